@@ -1,0 +1,27 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU checker (oracle/liboracle.so), built on demand.  Tests only."""
+    from tests import oracle_api
+
+    return oracle_api.load()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,60 @@
+"""Pins oracle/pairhmm_oracle.c against the reference's own KAT (test.in -> test.out) and against
+outputs of the unmodified reference programs on the reference corpus 10s.in (see make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import accelerating_genomics_amd.synth as synth
+
+NAMES = ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"]
+
+
+def g17(golden_dir, name):
+    return np.array([float(x) for x in open(os.path.join(golden_dir, name + ".g17.out")).read().split()])
+
+
+def test_reference_kat_file_is_the_reference_fixture(golden_dir):
+    assert open(os.path.join(golden_dir, "phmm_test.out")).read() == "-4.485565\n"
+    assert open(os.path.join(golden_dir, "phmm_test.f.out")).read() == "-4.485565\n"
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_f64_oracle_is_bit_identical_to_reference(oracle, golden_dir, name, variant):
+    ref = g17(golden_dir, name)
+    _, l = oracle.phmm_file(os.path.join(golden_dir, name + ".in"), variant=variant)
+    assert l.size == ref.size
+    assert np.array_equal(l, ref)  # %.17g round-trips doubles: bitwise equality
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_text_output_matches(oracle, golden_dir, name):
+    _, l = oracle.phmm_file(os.path.join(golden_dir, name + ".in"))
+    txt = "".join("%f\n" % v for v in l)
+    assert txt == open(os.path.join(golden_dir, name + ".f.out")).read()
+
+
+def test_corpus_shape(oracle, golden_dir):
+    b = synth.parse_phmm_text(open(os.path.join(golden_dir, "phmm_10s.in"), "rb").read())
+    assert b.n_regions == 7 and b.n_pairs == 3550 and b.cells() == 62_380_634
+    s, l = oracle.phmm_batch(b)
+    assert np.array_equal(l, g17(golden_dir, "phmm_10s"))
+
+
+def test_f32_restatement_within_1e6_of_f64_on_corpus(oracle, golden_dir):
+    """BASELINE config 3 tolerance (1e-6 relative on the log10-likelihood); SURVEY.md Q12 measured 5.3e-7."""
+    b = synth.parse_phmm_text(open(os.path.join(golden_dir, "phmm_10s.in"), "rb").read())
+    _, l64 = oracle.phmm_batch(b, 0)
+    _, l32 = oracle.phmm_batch(b, 2)
+    assert np.all(np.isfinite(l32))
+    assert np.max(np.abs((l32 - l64) / l64)) < 1e-6
+
+
+def test_f32_underflows_on_unrelated_pairs(oracle, golden_dir):
+    """The reason the product needs an fp64 rescue path: unrelated pairs sit near 1e-96."""
+    b = synth.parse_phmm_text(open(os.path.join(golden_dir, "phmm_far.in"), "rb").read())
+    s32, _ = oracle.phmm_batch(b, 2)
+    _, l64 = oracle.phmm_batch(b, 0)
+    assert np.all(l64 < -90)
+    assert np.all(s32 < 1e-30)  # denormal / zero in float

@@ -1,0 +1,57 @@
+"""Pins oracle/sw_oracle.c against outputs of the unmodified reference program
+(tests/golden/sw_*.expect, made by oracle/_ref/sw_ref; see make_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import accelerating_genomics_amd.synth as synth
+
+
+def expect_scores(path):
+    lines = open(path, "rb").read().splitlines()
+    assert lines[0].startswith(b"line_num: ")
+    return int(lines[0].split()[1]), np.array([int(l.split()[1]) for l in lines[1:] if l.startswith(b"Score: ")], np.int32)
+
+
+CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sw_*.in")))
+
+
+def test_cases_present():
+    assert len(CASES) >= 10
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_oracle_matches_reference_output(oracle, golden_dir, name, variant):
+    n_ref, s_ref = expect_scores(os.path.join(golden_dir, name + ".expect"))
+    n, s = oracle.sw_file(os.path.join(golden_dir, name + ".in"), variant=variant)
+    assert n == n_ref
+    assert np.array_equal(s, s_ref)  # bit-exact: integer work
+
+
+def test_survey_kats(oracle, golden_dir):
+    # SURVEY.md section 4 micro-KATs, measured on the reference binary
+    _, s = oracle.sw_file(os.path.join(golden_dir, "sw_kat.in"))
+    assert list(s[:6]) == [5, 2, 1, 5, 6, 2]
+    _, s = oracle.sw_file(os.path.join(golden_dir, "sw_nofinalnl.in"))
+    assert s[0] == 5  # both lines end in '\n'
+    b = synth.sw_from_seqs([b"ACGT\n", b"ACGT"])  # last line of a file without final newline: no sentinel
+    assert list(oracle.sw_batch(b)) == [4]
+
+
+def test_variants_agree_on_random_and_related_pairs(oracle):
+    b = synth.sw_pairs(300, 1, 200, seed=123, related_frac=0.5)
+    assert np.array_equal(oracle.sw_batch(b, 0), oracle.sw_batch(b, 1))
+
+
+def test_negative_infinity_is_equivalent_to_a_small_constant(oracle):
+    """P/Q never propagate -inf past the boundary cell, so padding the
+    matrix with never-matching symbols leaves the score unchanged -- the property the HIP
+    kernel's lane/row padding relies on.  Checked here by padding with unused bytes."""
+    b = synth.sw_pairs(64, 5, 60, seed=5, related_frac=0.5, newline=False)
+    seqs = []
+    for p in range(b.n_pairs):
+        seqs += [b"\x01" * 3 + b.seq(2 * p) + b"\x01" * 5, b"\x02" * 4 + b.seq(2 * p + 1) + b"\x02" * 2]
+    assert np.array_equal(oracle.sw_batch(synth.sw_from_seqs(seqs)), oracle.sw_batch(b))
