@@ -1,0 +1,315 @@
+"""ctypes view of libagx.so (include/agx.h).  No compute happens in Python and there is no
+fallback: if the library or a HIP device is missing, calls raise AgxError."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libagx.so")
+
+OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_SYMBOL, E_LIMIT, E_IO = 0, -1, -2, -3, -4, -5, -6, -7
+PHMM_F64, PHMM_F64_FMA, PHMM_F32 = 0, 1, 2
+
+# every symbol include/agx.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "agx_version", "agx_last_error", "agx_device_count", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
+    "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_timer_start", "agx_ctx_timer_stop",
+    "agx_sw_batch_create", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
+    "agx_sw_score", "agx_sw_score_multi",
+    "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
+    "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_pairHMM",
+    "agx_sw_text_read", "agx_sw_text_free", "agx_phmm_text_read", "agx_phmm_text_free",
+]
+
+
+class AgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("agx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SwInfo(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("cells", C.c_int64), ("padded_cells", C.c_int64), ("input_bytes", C.c_int64),
+                ("n_launches", C.c_int32), ("n_waves", C.c_int32)]
+
+
+class PhmmDesc(C.Structure):
+    _fields_ = [("read_bases", C.c_void_p), ("q_base", C.c_void_p), ("q_ins", C.c_void_p), ("q_del", C.c_void_p),
+                ("q_gcp", C.c_void_p), ("read_off", C.c_void_p), ("n_reads", C.c_uint32),
+                ("hap_bases", C.c_void_p), ("hap_off", C.c_void_p), ("n_haps", C.c_uint32),
+                ("region_read", C.c_void_p), ("region_hap", C.c_void_p), ("n_regions", C.c_uint32)]
+
+
+class PhmmInfo(C.Structure):
+    _fields_ = [("n_pairs", C.c_int64), ("cells", C.c_int64), ("padded_cells", C.c_int64), ("input_bytes", C.c_int64),
+                ("n_launches", C.c_int32), ("n_waves", C.c_int32), ("n_rescued", C.c_int64)]
+
+
+class SwText(C.Structure):
+    _fields_ = [("line_num", C.c_int32), ("n_pairs", C.c_int64), ("bases", C.c_void_p), ("off", C.c_void_p),
+                ("len", C.c_void_p), ("dangling", C.c_char_p)]
+
+
+class PhmmText(C.Structure):
+    _fields_ = [("desc", PhmmDesc), ("n_pairs", C.c_int64), ("n_regions_seen", C.c_int32), ("truncated", C.c_int32)]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libagx.so and the drop-in command lines for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", _HERE, "-j8", "all"], check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AgxError(E_NODEVICE, "libagx.so is not built (run __graft_entry__.build()); there is no fallback")
+        l = C.CDLL(LIB_PATH)
+        l.agx_version.restype = C.c_char_p
+        l.agx_last_error.restype = C.c_char_p
+        l.agx_ctx_stream.restype = C.c_void_p
+        l.agx_ctx_stream.argtypes = [C.c_void_p]
+        l.agx_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.agx_ctx_destroy.argtypes = [C.c_void_p]
+        l.agx_ctx_destroy.restype = None
+        l.agx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        l.agx_ctx_sync.argtypes = [C.c_void_p]
+        l.agx_ctx_timer_start.argtypes = [C.c_void_p]
+        l.agx_ctx_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.agx_sw_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.POINTER(C.c_void_p)]
+        l.agx_sw_batch_launch.argtypes = [C.c_void_p]
+        l.agx_sw_batch_scores.argtypes = [C.c_void_p, C.c_void_p]
+        l.agx_sw_batch_info.argtypes = [C.c_void_p, C.POINTER(SwInfo)]
+        l.agx_sw_batch_destroy.argtypes = [C.c_void_p]
+        l.agx_sw_batch_destroy.restype = None
+        l.agx_sw_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.agx_sw_score_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.agx_phmm_batch_create.argtypes = [C.c_void_p, C.POINTER(PhmmDesc), C.c_int, C.POINTER(C.c_void_p)]
+        l.agx_phmm_batch_launch.argtypes = [C.c_void_p]
+        l.agx_phmm_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.agx_phmm_batch_info.argtypes = [C.c_void_p, C.POINTER(PhmmInfo)]
+        l.agx_phmm_batch_destroy.argtypes = [C.c_void_p]
+        l.agx_phmm_batch_destroy.restype = None
+        l.agx_phmm_forward.argtypes = [C.c_void_p, C.POINTER(PhmmDesc), C.c_int, C.c_void_p]
+        l.agx_phmm_forward_multi.argtypes = [C.c_int, C.POINTER(PhmmDesc), C.c_int, C.c_void_p]
+        l.agx_pairHMM.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+        l.agx_pairHMM.restype = None
+        l.agx_sw_text_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(SwText))]
+        l.agx_sw_text_free.argtypes = [C.POINTER(SwText)]
+        l.agx_sw_text_free.restype = None
+        l.agx_phmm_text_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(PhmmText))]
+        l.agx_phmm_text_free.argtypes = [C.POINTER(PhmmText)]
+        l.agx_phmm_text_free.restype = None
+        _lib = l
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise AgxError(rc, lib().agx_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    return lib().agx_device_count()
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None and a.size else None
+
+
+class Context:
+    """agx_ctx: one device, one HIP stream."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().agx_ctx_create(device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().agx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return lib().agx_ctx_stream(self._h) or 0
+
+    def set_stream(self, hip_stream: int):
+        _check(lib().agx_ctx_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def sync(self):
+        _check(lib().agx_ctx_sync(self._h))
+
+    def timer_start(self):
+        _check(lib().agx_ctx_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _check(lib().agx_ctx_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- Smith-Waterman
+    def sw_batch(self, b) -> "SwBatch":
+        return SwBatch(self, b)
+
+    def sw_score(self, b) -> np.ndarray:
+        """b: synth.SWBatch (bases/off/len) -> int32 scores, one-shot."""
+        out = np.empty(b.n_pairs, np.int32)
+        _check(lib().agx_sw_score(self._h, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs, _ptr(out)))
+        return out
+
+    # ---- PairHMM
+    def phmm_batch(self, b, precision=PHMM_F64) -> "PhmmBatchDev":
+        return PhmmBatchDev(self, b, precision)
+
+    def phmm_forward(self, b, precision=PHMM_F64) -> np.ndarray:
+        out = np.empty(b.n_pairs, np.float64)
+        d, _keep = phmm_desc(b)
+        _check(lib().agx_phmm_forward(self._h, C.byref(d), precision, _ptr(out)))
+        return out
+
+
+class SwBatch:
+    """agx_sw_batch: a scheduled batch resident in HBM."""
+
+    def __init__(self, ctx: Context, b):
+        self.ctx = ctx
+        self.n_pairs = b.n_pairs
+        self._h = C.c_void_p()
+        _check(lib().agx_sw_batch_create(ctx._h, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs, C.byref(self._h)))
+
+    def launch(self):
+        _check(lib().agx_sw_batch_launch(self._h))
+
+    def scores(self) -> np.ndarray:
+        out = np.empty(self.n_pairs, np.int32)
+        _check(lib().agx_sw_batch_scores(self._h, _ptr(out)))
+        return out
+
+    def info(self) -> SwInfo:
+        i = SwInfo()
+        _check(lib().agx_sw_batch_info(self._h, C.byref(i)))
+        return i
+
+    def close(self):
+        if self._h:
+            lib().agx_sw_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def phmm_desc(b):
+    """synth.PhmmBatch -> (PhmmDesc, keepalive)."""
+    d = PhmmDesc()
+    d.read_bases, d.q_base, d.q_ins, d.q_del, d.q_gcp = (_ptr(x) for x in (b.read_bases, b.q_base, b.q_ins, b.q_del, b.q_gcp))
+    d.read_off = _ptr(b.roff)
+    d.n_reads = b.roff.size - 1
+    d.hap_bases = _ptr(b.hap_bases)
+    d.hap_off = _ptr(b.hoff)
+    d.n_haps = b.hoff.size - 1
+    d.region_read = _ptr(b.rreg)
+    d.region_hap = _ptr(b.hreg)
+    d.n_regions = b.n_regions
+    return d, b
+
+
+class PhmmBatchDev:
+    """agx_phmm_batch: a scheduled PairHMM batch resident in HBM."""
+
+    def __init__(self, ctx: Context, b, precision=PHMM_F64):
+        self.ctx = ctx
+        self.n_pairs = b.n_pairs
+        self._h = C.c_void_p()
+        d, self._keep = phmm_desc(b)
+        _check(lib().agx_phmm_batch_create(ctx._h, C.byref(d), precision, C.byref(self._h)))
+
+    def launch(self):
+        _check(lib().agx_phmm_batch_launch(self._h))
+
+    def results(self):
+        """-> (log10 likelihoods, raw sums), float64."""
+        l = np.empty(self.n_pairs, np.float64)
+        s = np.empty(self.n_pairs, np.float64)
+        _check(lib().agx_phmm_batch_results(self._h, _ptr(l), _ptr(s)))
+        return l, s
+
+    def info(self) -> PhmmInfo:
+        i = PhmmInfo()
+        _check(lib().agx_phmm_batch_info(self._h, C.byref(i)))
+        return i
+
+    def close(self):
+        if self._h:
+            lib().agx_phmm_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def sw_score_multi(b, n_devices: int = 0) -> np.ndarray:
+    out = np.empty(b.n_pairs, np.int32)
+    _check(lib().agx_sw_score_multi(n_devices, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs, _ptr(out)))
+    return out
+
+
+def phmm_forward_multi(b, precision=PHMM_F64, n_devices: int = 0) -> np.ndarray:
+    out = np.empty(b.n_pairs, np.float64)
+    d, _keep = phmm_desc(b)
+    _check(lib().agx_phmm_forward_multi(n_devices, C.byref(d), precision, _ptr(out)))
+    return out
+
+
+def read_sw_text(path: str, line_buf: int = 0):
+    """agx_sw_text_read -> (line_num, synth.SWBatch, dangling line or None)."""
+    from . import synth
+
+    t = C.POINTER(SwText)()
+    _check(lib().agx_sw_text_read(path.encode(), line_buf, C.byref(t)))
+    try:
+        n = t.contents.n_pairs
+        off = np.ctypeslib.as_array(C.cast(t.contents.off, C.POINTER(C.c_uint64)), shape=(2 * n,)).copy() if n else np.zeros(0, np.uint64)
+        ln = np.ctypeslib.as_array(C.cast(t.contents.len, C.POINTER(C.c_uint32)), shape=(2 * n,)).copy() if n else np.zeros(0, np.uint32)
+        total = int(off[-1] + ln[-1]) if n else 0
+        bases = np.ctypeslib.as_array(C.cast(t.contents.bases, C.POINTER(C.c_uint8)), shape=(total,)).copy() if total else np.zeros(0, np.uint8)
+        return t.contents.line_num, synth.SWBatch(bases, off, ln), t.contents.dangling
+    finally:
+        lib().agx_sw_text_free(t)
+
+
+def read_phmm_text(path: str):
+    """agx_phmm_text_read -> (synth.PhmmBatch, n_regions_seen, truncated)."""
+    from . import synth
+
+    t = C.POINTER(PhmmText)()
+    _check(lib().agx_phmm_text_read(path.encode(), C.byref(t)))
+    try:
+        d = t.contents.desc
+        arr = lambda p, ty, n: (np.ctypeslib.as_array(C.cast(p, C.POINTER(ty)), shape=(n,)).copy() if n else np.zeros(0, ty))
+        roff = arr(d.read_off, C.c_uint64, d.n_reads + 1)
+        hoff = arr(d.hap_off, C.c_uint64, d.n_haps + 1)
+        nb, nh = int(roff[-1]), int(hoff[-1])
+        b = synth.PhmmBatch(arr(d.read_bases, C.c_uint8, nb), arr(d.q_base, C.c_uint8, nb), arr(d.q_ins, C.c_uint8, nb),
+                            arr(d.q_del, C.c_uint8, nb), arr(d.q_gcp, C.c_uint8, nb), roff,
+                            arr(d.hap_bases, C.c_uint8, nh), hoff, arr(d.region_read, C.c_uint32, d.n_regions + 1),
+                            arr(d.region_hap, C.c_uint32, d.n_regions + 1))
+        return b, t.contents.n_regions_seen, t.contents.truncated
+    finally:
+        lib().agx_phmm_text_free(t)

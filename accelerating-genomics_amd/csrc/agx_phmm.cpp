@@ -1,0 +1,519 @@
+// Host side of the PairHMM path: validation, lane-tiling choice, packing, launches, the final
+// log10 (host libm, as the reference does), multi-device sharding, and the pairHMM() seam
+// (include/agx.h, "PairHMM" section).
+#include "agx_phmm.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "agx_internal.h"
+
+namespace {
+
+constexpr size_t kTabBudget = 16 * 1024; // LDS bytes a wave may spend on several read tables
+constexpr uint32_t kHapSlack = 32;       // zero bytes after every haplotype: any tiling reads in bounds
+
+struct Plan {
+    uint32_t out;
+    uint32_t read, hap;
+    uint32_t R, H;
+    uint8_t cls;
+    uint8_t G;
+};
+
+struct ClassLaunch {
+    int C = 0;
+    uint32_t first_wave = 0, n_waves = 0;
+    size_t lds = 0;        // dynamic LDS of the fill in the batch's precision
+    size_t lds_rescue = 0; // same tables with double rows (F32 rescue pass)
+};
+
+void choose_tiling(uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
+{
+    int best = -1, bestG = 0;
+    double best_cost = 0;
+    for (int ci = 0; ci < kPhNumClasses; ++ci) {
+        const int C = kPhClasses[ci];
+        const int G = (int)((H + C - 1) / C);
+        if (G > 64) continue;
+        const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G));
+        if (best < 0 || cost < best_cost) {
+            best = ci;
+            bestG = G;
+            best_cost = cost;
+        }
+    }
+    *cls = (uint8_t)best;
+    *G_out = (uint8_t)bestG;
+}
+
+// 256-entry quality LUT exactly as partition_read() computes it (antidiagsPairHMM.c:104-107)
+void build_lut(double *d, float *f)
+{
+    for (int c = 0; c < 256; ++c) {
+        d[c] = pow(10.0, -(c - 33.0) * 0.1);
+        f[c] = (float)d[c];
+    }
+}
+
+} // namespace
+
+struct agx_phmm_batch {
+    agx_ctx *ctx = nullptr;
+    int precision = AGX_PHMM_F64;
+    bool probs = false; // read tracks are probabilities (pairHMM() seam), not Phred characters
+    int64_t n_pairs = 0;
+    DevBuf img, groups, tabs, waves, sums, lut, counter;
+    std::vector<ClassLaunch> launches;
+    agx_phmm_info info{};
+};
+
+namespace {
+
+// Shared by the byte-track API and the probability-track seam.  When prob[] is non-NULL it holds
+// the four probability tracks of every read (Qr,Qi,Qd,Qg concatenated per read, read_off units).
+int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[4], int precision, agx_phmm_batch **out)
+{
+    if (!out) {
+        agx_set_error("agx_phmm_batch_create: out is NULL");
+        return AGX_E_ARG;
+    }
+    *out = nullptr;
+    int rc = agx_bind(ctx);
+    if (rc) return rc;
+    if (!d || precision < AGX_PHMM_F64 || precision > AGX_PHMM_F32) {
+        agx_set_error("agx_phmm_batch_create: bad descriptor or precision %d", precision);
+        return AGX_E_ARG;
+    }
+    if (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off)) {
+        agx_set_error("agx_phmm_batch_create: NULL offset table");
+        return AGX_E_ARG;
+    }
+    const bool f64 = precision != AGX_PHMM_F32;
+    const bool probs = prob != nullptr;
+    if (probs && precision != AGX_PHMM_F64) {
+        agx_set_error("probability tracks are only supported with AGX_PHMM_F64");
+        return AGX_E_ARG;
+    }
+
+    // ---- plan
+    std::vector<Plan> plan;
+    int64_t n_pairs = 0, cells = 0;
+    for (uint32_t g = 0; g < d->n_regions; ++g) {
+        const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
+        const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+        if (r1 < r0 || h1 < h0 || r1 > d->n_reads || h1 > d->n_haps) {
+            agx_set_error("region %u: read/haplotype ranges out of order or out of bounds", g);
+            return AGX_E_ARG;
+        }
+        for (uint32_t r = r0; r < r1; ++r) {
+            const uint64_t R = d->read_off[r + 1] - d->read_off[r];
+            for (uint32_t h = h0; h < h1; ++h) {
+                const uint64_t H = d->hap_off[h + 1] - d->hap_off[h];
+                if (R > AGX_PHMM_MAX_READ_LEN || H > AGX_PHMM_MAX_HAP_LEN) {
+                    agx_set_error("pair (read %u, hap %u): %llu x %llu exceeds the supported %d x %d", r, h,
+                                  (unsigned long long)R, (unsigned long long)H, AGX_PHMM_MAX_READ_LEN, AGX_PHMM_MAX_HAP_LEN);
+                    return AGX_E_LIMIT;
+                }
+                Plan p{};
+                p.out = (uint32_t)n_pairs++;
+                cells += (int64_t)(R * H);
+                if (R == 0 || H == 0) continue; // sum over an empty row/all-zero row is 0 (log10 -> -inf)
+                p.read = r;
+                p.hap = h;
+                p.R = (uint32_t)R;
+                p.H = (uint32_t)H;
+                choose_tiling(p.R, p.H, &p.cls, &p.G);
+                plan.push_back(p);
+            }
+        }
+        if (n_pairs > 0x7fffffffLL) {
+            agx_set_error("more than 2^31 pairs in one batch");
+            return AGX_E_LIMIT;
+        }
+    }
+    std::sort(plan.begin(), plan.end(), [](const Plan &a, const Plan &b) {
+        if (a.cls != b.cls) return a.cls < b.cls;
+        if (a.G != b.G) return a.G > b.G;
+        if (a.read != b.read) return a.read < b.read; // haplotypes of one read stay adjacent: one LDS table
+        return a.hap < b.hap;
+    });
+
+    // ---- image: every read and haplotype once
+    std::vector<uint32_t> img;
+    std::vector<uint32_t> read_dw(d->n_reads, 0xffffffffu), hap_dw(d->n_haps, 0xffffffffu);
+    auto put_read = [&](uint32_t r) -> int {
+        if (read_dw[r] != 0xffffffffu) return 0;
+        const uint64_t o = d->read_off[r];
+        const uint32_t R = (uint32_t)(d->read_off[r + 1] - o);
+        const size_t trk = ((size_t)R + 3) / 4;
+        if (probs) {
+            if (img.size() & 1) img.push_back(0u); // doubles need 8-byte alignment
+            read_dw[r] = (uint32_t)img.size();
+            img.resize(img.size() + (size_t)R * 8 + trk, 0u);
+            double *q = reinterpret_cast<double *>(&img[read_dw[r]]);
+            for (int k = 0; k < 4; ++k) memcpy(q + (size_t)k * R, prob[k] + o, (size_t)R * sizeof(double));
+            memcpy(reinterpret_cast<uint8_t *>(q + (size_t)4 * R), d->read_bases + o, R);
+        } else {
+            read_dw[r] = (uint32_t)img.size();
+            img.resize(img.size() + 5 * trk, 0u);
+            uint8_t *p = reinterpret_cast<uint8_t *>(&img[read_dw[r]]);
+            const uint8_t *src[5] = {d->read_bases, d->q_base, d->q_ins, d->q_del, d->q_gcp};
+            for (int k = 0; k < 5; ++k) memcpy(p + (size_t)k * trk * 4, src[k] + o, R);
+        }
+        return 0;
+    };
+    auto put_hap = [&](uint32_t h) {
+        if (hap_dw[h] != 0xffffffffu) return;
+        const uint64_t o = d->hap_off[h];
+        const uint32_t H = (uint32_t)(d->hap_off[h + 1] - o);
+        hap_dw[h] = (uint32_t)img.size();
+        img.resize(img.size() + ((size_t)H + kHapSlack + 3) / 4, 0u);
+        memcpy(reinterpret_cast<uint8_t *>(&img[hap_dw[h]]), d->hap_bases + o, H);
+    };
+    if (!plan.empty()) {
+        if (!d->read_bases || !d->hap_bases || (!probs && (!d->q_base || !d->q_ins || !d->q_del || !d->q_gcp))) {
+            agx_set_error("agx_phmm_batch_create: NULL track");
+            return AGX_E_ARG;
+        }
+    }
+
+    // ---- waves
+    std::vector<PhGroup> groups(plan.size());
+    std::vector<PhTab> tabs;
+    std::vector<PhWave> waves;
+    std::vector<ClassLaunch> launches;
+    int64_t padded = 0;
+    size_t i = 0;
+    while (i < plan.size()) {
+        const int cls = plan[i].cls;
+        ClassLaunch cl;
+        cl.C = kPhClasses[cls];
+        cl.first_wave = (uint32_t)waves.size();
+        while (i < plan.size() && plan[i].cls == cls) {
+            const int G = plan[i].G;
+            const int per_wave = 64 / G;
+            PhWave w{};
+            w.first_group = (uint32_t)i;
+            w.first_tab = (uint32_t)tabs.size();
+            w.G = (uint16_t)G;
+            int n = 0;
+            uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
+            while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
+                const Plan &p = plan[i];
+                const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
+                const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
+                if (n > 0 && ntabs_new > 1 && ph_tab_bytes(f64, nsteps + G - 1) * ntabs_new > kTabBudget) break;
+                if (p.read != last_read) {
+                    put_read(p.read);
+                    tabs.push_back(PhTab{read_dw[p.read], p.R});
+                    last_read = p.read;
+                }
+                put_hap(p.hap);
+                if (img.size() > 0xfffffff0ull) {
+                    agx_set_error("packed image exceeds 16 GiB; split the batch");
+                    return AGX_E_LIMIT;
+                }
+                ntabs = ntabs_new;
+                steps = nsteps;
+                PhGroup g{};
+                g.hap_dw = hap_dw[p.hap];
+                g.H = p.H;
+                g.R_tab = p.R | ((ntabs - 1) << 16);
+                g.out = p.out;
+                g.init64 = DBL_MAX / 16 / (double)p.H;
+                g.init32 = FLT_MAX / 16 / (float)p.H;
+                groups[i] = g;
+                ++n;
+                ++i;
+            }
+            w.n_groups = (uint16_t)n;
+            w.n_tabs = (uint16_t)ntabs;
+            w.steps = steps;
+            cl.lds = std::max(cl.lds, ph_tab_bytes(f64, steps + G - 1) * ntabs);
+            cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, steps + G - 1) * ntabs);
+            padded += (int64_t)steps * 64 * cl.C;
+            waves.push_back(w);
+        }
+        cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
+        if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
+            agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
+            return AGX_E_LIMIT;
+        }
+        launches.push_back(cl);
+    }
+
+    // ---- upload
+    agx_phmm_batch *b = new agx_phmm_batch();
+    b->ctx = ctx;
+    b->precision = precision;
+    b->probs = probs;
+    b->n_pairs = n_pairs;
+    b->launches = launches;
+    b->info.n_pairs = n_pairs;
+    b->info.cells = cells;
+    b->info.padded_cells = padded;
+    b->info.input_bytes = (int64_t)(img.size() * 4 + groups.size() * sizeof(PhGroup) + tabs.size() * sizeof(PhTab) +
+                                    waves.size() * sizeof(PhWave));
+    b->info.n_launches = (int32_t)launches.size() * (precision == AGX_PHMM_F32 ? 2 : 1);
+    b->info.n_waves = (int32_t)waves.size();
+    double lut_d[256];
+    float lut_f[256];
+    build_lut(lut_d, lut_f);
+    rc = b->img.alloc(img.size() * 4);
+    if (!rc) rc = b->groups.alloc(groups.size() * sizeof(PhGroup));
+    if (!rc) rc = b->tabs.alloc(tabs.size() * sizeof(PhTab));
+    if (!rc) rc = b->waves.alloc(waves.size() * sizeof(PhWave));
+    if (!rc) rc = b->sums.alloc((size_t)n_pairs * sizeof(double));
+    if (!rc) rc = b->lut.alloc(sizeof lut_d + sizeof lut_f);
+    if (!rc) rc = b->counter.alloc(sizeof(unsigned long long));
+    if (rc) {
+        agx_phmm_batch_destroy(b);
+        return rc;
+    }
+    hipError_t e = hipSuccess;
+    auto up = [&](DevBuf &dst, const void *src, size_t n) {
+        if (e == hipSuccess && n) e = hipMemcpy(dst.p, src, n, hipMemcpyHostToDevice);
+    };
+    up(b->img, img.data(), img.size() * 4);
+    up(b->groups, groups.data(), groups.size() * sizeof(PhGroup));
+    up(b->tabs, tabs.data(), tabs.size() * sizeof(PhTab));
+    up(b->waves, waves.data(), waves.size() * sizeof(PhWave));
+    up(b->lut, lut_d, sizeof lut_d);
+    if (e == hipSuccess) e = hipMemcpy((char *)b->lut.p + sizeof lut_d, lut_f, sizeof lut_f, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(b->sums.p, 0, b->sums.bytes); // degenerate pairs keep sum 0
+    if (e == hipSuccess) e = hipMemset(b->counter.p, 0, b->counter.bytes);
+    if (e != hipSuccess) {
+        agx_set_error("agx_phmm_batch_create: upload -> %s", hipGetErrorString(e));
+        agx_phmm_batch_destroy(b);
+        return AGX_E_HIP;
+    }
+    *out = b;
+    return AGX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void agx_phmm_batch_destroy(agx_phmm_batch *b)
+{
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    b->img.release();
+    b->groups.release();
+    b->tabs.release();
+    b->waves.release();
+    b->sums.release();
+    b->lut.release();
+    b->counter.release();
+    delete b;
+}
+
+int agx_phmm_batch_create(agx_ctx *ctx, const agx_phmm_desc *d, int precision, agx_phmm_batch **out)
+{
+    return create_batch(ctx, d, nullptr, precision, out);
+}
+
+int agx_phmm_batch_launch(agx_phmm_batch *b)
+{
+    if (!b) {
+        agx_set_error("agx_phmm_batch_launch: null batch");
+        return AGX_E_ARG;
+    }
+    int rc = agx_bind(b->ctx);
+    if (rc) return rc;
+    hipStream_t s = b->ctx->stream;
+    const void *lut_d = b->lut.p;
+    const void *lut_f = (const char *)b->lut.p + 256 * sizeof(double);
+    const int passes = b->precision == AGX_PHMM_F32 ? 2 : 1;
+    if (passes == 2) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
+    for (int pass = 0; pass < passes; ++pass) {
+        // F32: pass 0 = float fill, pass 1 = double recomputation of the pairs that underflowed
+        int mode = b->precision;
+        if (b->probs) mode = 4;
+        if (pass == 1) mode = 3;
+        for (const ClassLaunch &cl : b->launches) {
+            const bool f64 = mode != 2;
+            const size_t lds = pass == 1 ? cl.lds_rescue : cl.lds; // same records, wider table rows
+            const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->groups.p,
+                                                (const PhTab *)b->tabs.p, (const PhWave *)b->waves.p + cl.first_wave,
+                                                cl.n_waves, f64 ? lut_d : lut_f, (double *)b->sums.p,
+                                                (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, s);
+            if (r) {
+                agx_set_error("phmm_fill<C=%d, mode %d> launch failed: %s", cl.C, mode, hipGetErrorString(hipGetLastError()));
+                return AGX_E_HIP;
+            }
+        }
+    }
+    return AGX_OK;
+}
+
+int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum)
+{
+    if (!b || (!log10_lik && b->n_pairs)) {
+        agx_set_error("agx_phmm_batch_results: null argument");
+        return AGX_E_ARG;
+    }
+    int rc = agx_bind(b->ctx);
+    if (rc) return rc;
+    AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+    std::vector<double> tmp;
+    double *s = raw_sum;
+    if (!s) {
+        tmp.resize((size_t)b->n_pairs);
+        s = tmp.data();
+    }
+    if (b->n_pairs) AGX_HIP(hipMemcpy(s, b->sums.p, (size_t)b->n_pairs * sizeof(double), hipMemcpyDeviceToHost));
+    unsigned long long nres = 0;
+    AGX_HIP(hipMemcpy(&nres, b->counter.p, sizeof nres, hipMemcpyDeviceToHost));
+    b->info.n_rescued = (int64_t)nres;
+    // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
+    const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
+    const bool f32 = b->precision == AGX_PHMM_F32;
+    for (int64_t k = 0; k < b->n_pairs; ++k) {
+        double v = s[k];
+        if (f32) {
+            // the rescue pass stores its double-scaled sum negated so the two scalings stay apart
+            if (std::signbit(v) && v != 0) {
+                v = -v;
+                log10_lik[k] = log10(v) - c64;
+            } else {
+                log10_lik[k] = log10(v) - c32;
+            }
+            s[k] = v;
+        } else {
+            log10_lik[k] = log10(v) - c64;
+        }
+    }
+    return AGX_OK;
+}
+
+int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info)
+{
+    if (!b || !info) {
+        agx_set_error("agx_phmm_batch_info: null argument");
+        return AGX_E_ARG;
+    }
+    *info = b->info;
+    return AGX_OK;
+}
+
+int agx_phmm_forward(agx_ctx *ctx, const agx_phmm_desc *d, int precision, double *log10_lik)
+{
+    agx_phmm_batch *b = nullptr;
+    int rc = agx_phmm_batch_create(ctx, d, precision, &b);
+    if (rc) return rc;
+    rc = agx_phmm_batch_launch(b);
+    if (!rc) rc = agx_phmm_batch_results(b, log10_lik, nullptr);
+    agx_phmm_batch_destroy(b);
+    return rc;
+}
+
+int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik)
+{
+    const int avail = agx_device_count();
+    if (avail <= 0) {
+        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
+        return AGX_E_NODEVICE;
+    }
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    if (!d || (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off || !log10_lik))) {
+        agx_set_error("agx_phmm_forward_multi: bad arguments");
+        return AGX_E_ARG;
+    }
+    // whole regions stay together; contiguous shards balanced by cells
+    const uint32_t ng = d->n_regions;
+    std::vector<double> cost(ng);
+    std::vector<int64_t> first_out(ng + 1, 0);
+    double total = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+        const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+        if (r1 < r0 || h1 < h0 || r1 > d->n_reads || h1 > d->n_haps) {
+            agx_set_error("region %u: ranges out of order or out of bounds", g);
+            return AGX_E_ARG;
+        }
+        const double rb = (double)(d->read_off[r1] - d->read_off[r0]), hb = (double)(d->hap_off[h1] - d->hap_off[h0]);
+        cost[g] = rb * hb + 1.0;
+        total += cost[g];
+        first_out[g + 1] = first_out[g] + (int64_t)(r1 - r0) * (h1 - h0);
+    }
+    std::vector<uint32_t> cut(n_devices + 1, ng);
+    cut[0] = 0;
+    {
+        double acc = 0;
+        int k = 1;
+        for (uint32_t g = 0; g < ng && k < n_devices; ++g) {
+            acc += cost[g];
+            while (k < n_devices && acc >= total * k / n_devices) cut[k++] = g + 1;
+        }
+    }
+    std::vector<int> rcs(n_devices, AGX_OK);
+    std::vector<std::string> errs(n_devices);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_devices; ++k) {
+        th.emplace_back([&, k]() {
+            const uint32_t lo = cut[k], hi = cut[k + 1];
+            if (hi <= lo) return;
+            agx_phmm_desc sub = *d;
+            sub.region_read = d->region_read + lo; // absolute read/hap indices stay valid
+            sub.region_hap = d->region_hap + lo;
+            sub.n_regions = hi - lo;
+            agx_ctx *c = nullptr;
+            int rc = agx_ctx_create(k, &c);
+            if (!rc) rc = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
+            if (rc) errs[k] = agx_last_error();
+            agx_ctx_destroy(c);
+            rcs[k] = rc;
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; ++k)
+        if (rcs[k]) {
+            agx_set_error("device %d: %s", k, errs[k].c_str());
+            return rcs[k];
+        }
+    return AGX_OK;
+}
+
+void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, char *H, int read_len, int haplotype_len,
+                 double *Qr, double *Qi, double *Qd, double *Qg)
+{
+    (void)M;
+    (void)X;
+    (void)Y; // the reference's rolling anti-diagonal scratch (antidiagsPairHMM.c:452-455): unused here
+    static std::mutex mu;
+    static agx_ctx *ctx = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!likelihood) return;
+    *likelihood = NAN;
+    if (read_len < 0 || haplotype_len < 0 || !R || !H || !Qr || !Qi || !Qd || !Qg) {
+        agx_set_error("agx_pairHMM: bad arguments");
+        return;
+    }
+    if (!ctx && agx_ctx_create(0, &ctx) != AGX_OK) return;
+    const uint64_t roff[2] = {0, (uint64_t)read_len}, hoff[2] = {0, (uint64_t)haplotype_len};
+    const uint32_t reg[2] = {0, 1};
+    agx_phmm_desc d{};
+    d.read_bases = reinterpret_cast<const uint8_t *>(R);
+    d.read_off = roff;
+    d.n_reads = 1;
+    d.hap_bases = reinterpret_cast<const uint8_t *>(H);
+    d.hap_off = hoff;
+    d.n_haps = 1;
+    d.region_read = reg;
+    d.region_hap = reg;
+    d.n_regions = 1;
+    const double *prob[4] = {Qr, Qi, Qd, Qg};
+    agx_phmm_batch *b = nullptr;
+    if (create_batch(ctx, &d, prob, AGX_PHMM_F64, &b) != AGX_OK) return;
+    double v = NAN;
+    if (agx_phmm_batch_launch(b) == AGX_OK && agx_phmm_batch_results(b, &v, nullptr) == AGX_OK) *likelihood = v;
+    agx_phmm_batch_destroy(b);
+}
+
+} // extern "C"

@@ -1,0 +1,50 @@
+// Device work records of the PairHMM forward fill (shared by scheduler and kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// One (read, haplotype) pair = one group of G lanes; lane g owns haplotype columns
+// [g*C+1, (g+1)*C].  hap_dw: 4-byte-word offset of the haplotype bases in the packed image
+// (zero-padded to G*C bytes).  tab: which of the wave's LDS read tables this pair uses.
+struct PhGroup {
+    uint32_t hap_dw;
+    uint32_t H;
+    uint32_t R_tab; // R | tab << 16
+    uint32_t out;   // index into sums[]
+    double init64;  // Y[0][j] = DBL_MAX/16/H, divided on the host (antidiagsPairHMM.c:135)
+    float init32;   // FLT_MAX/16/H for the float fill
+    uint32_t reserved;
+};
+
+// One read table to build in LDS: the read's five tracks start at read_dw, each padded to 4 bytes.
+struct PhTab {
+    uint32_t read_dw;
+    uint32_t R;
+};
+
+// One wavefront: n_groups groups of G lanes sharing n_tabs read tables, stepping `steps` rows
+// (>= max(R) + G - 1).  Every table has steps + G - 1 rows: G-1 neutral rows, the read, neutral tail.
+struct PhWave {
+    uint32_t first_group;
+    uint32_t first_tab;
+    uint16_t n_groups;
+    uint16_t n_tabs;
+    uint16_t G;
+    uint16_t reserved;
+    uint32_t steps;
+};
+
+static const int kPhClasses[] = {4, 8, 12, 16, 24, 32};
+static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
+
+// bytes of LDS one table row takes (four probabilities + the read base)
+__host__ __device__ static inline size_t ph_row_bytes(bool f64) { return (f64 ? 8u : 4u) * 4u + 1u; }
+__host__ __device__ static inline size_t ph_tab_bytes(bool f64, uint32_t rows) { return (ph_row_bytes(f64) * rows + 15u) & ~(size_t)15u; }
+
+// mode: 0 = f64 reference order, 1 = f64 with FMA contraction, 2 = f32, 3 = f64 rescue pass
+// over an f32 result (only groups whose sums[out] < rescue_below are recomputed), 4 = f64
+// reference order with probability tracks instead of Phred characters (pairHMM() seam).
+int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
+                          const PhWave *waves, uint32_t n_waves, const void *lut, double *sums, double rescue_below,
+                          unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s);

@@ -1,0 +1,252 @@
+// PairHMM forward recurrence for gfx950 (wave64).  Built with -ffp-contract=off: in the
+// reference-order modes every product and sum below rounds exactly once, like the
+// reference compiled for baseline x86-64; the FMA mode contracts explicitly.
+//
+// What it replaces: pairHMM() of pairHMM/antidiagsPairHMM.c:120-267 (same arithmetic as
+// pairHMM/pairHMMmatrix.c:41-66):
+//     M[i][j] = p(R[i-1],H[j-1],Qr[i-1]) * (mm(Qi,Qd)*M[i-1][j-1] + (1-Qg)*(X[i-1][j-1]+Y[i-1][j-1]))
+//     X[i][j] = M[i-1][j]*Qi + X[i-1][j]*Qg            Y[i][j] = M[i][j-1]*Qd + Y[i][j-1]*Qg
+//     sum = SUM_j (M[R][j] + X[R][j])     (row 0: M=X=0, Y=MAX/16/H; column 0 of rows>=1: 0)
+//
+// Schedule:
+//   * One (read, haplotype) pair per GROUP of G lanes (G chosen on the host, 1..64); lane g owns
+//     C haplotype columns (template parameter) and keeps their M/X/Y of the previous read row in
+//     VGPRs.  Read rows stream through the group skewed one step per lane -- the reference's
+//     anti-diagonal wavefront tiled C cells deep.  Left/diagonal neighbours of a lane's first
+//     column arrive from lane g-1 by DPP wave_shr:1; Y's in-row dependency is in-lane.
+//   * The "query profile" lives in LDS: per read one table {Qr,Qi,Qd,Qg as probabilities (94-entry
+//     pow(10,-q/10) LUT computed by the host libm, antidiagsPairHMM.c:104-107), base}, built once
+//     per wave and shared by all its groups that use the read.  Lane g reads row t-g each step.
+//   * No masks in the cell loop.  Rows a lane visits before its first / after its last real row
+//     are NEUTRAL table rows (Qi=Qd=0, Qg=1, so mm=1 and 1-Qg=0): they reproduce the row-0
+//     state (M=0, X=0, Y=init) exactly, so a lane that starts late finds the boundary it needs.
+//     Columns beyond H compute garbage that never flows left, and are skipped in the final sum.
+//   * The sum over the last row runs down the lanes in column order (one add per column, the
+//     reference's order), so in AGX_PHMM_F64 the raw sum is bit-identical to the reference.
+//
+// Bound: VALU issue (11 flops/cell in reference order, 8 with FMA); HBM traffic is the inputs
+// once per wave plus one double per pair.  See DESIGN.md.
+#include "agx_phmm.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ int shr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ float shr1(float v) { return __int_as_float(shr1i(__float_as_int(v))); }
+__device__ __forceinline__ double shr1(double v)
+{
+    return __hiloint2double(shr1i(__double2hiint(v)), shr1i(__double2loint(v)));
+}
+
+template <bool FMA> __device__ __forceinline__ double mad(double a, double b, double c)
+{
+    if constexpr (FMA) return __builtin_fma(a, b, c);
+    return a * b + c; // two roundings (file is built with contraction off)
+}
+template <bool FMA> __device__ __forceinline__ float mad(float a, float b, float c)
+{
+    if constexpr (FMA) return __builtin_fmaf(a, b, c);
+    return a * b + c;
+}
+
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+__global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
+                                                const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                                uint32_t n_waves, const T *__restrict__ lut, double *__restrict__ sums,
+                                                double rescue_below, unsigned long long *__restrict__ n_rescued)
+{
+    static_assert(C % 4 == 0, "columns per lane are loaded as packed dwords");
+    constexpr int HW = C / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t wave = blockIdx.x; // one wavefront per workgroup
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x;
+    const PhWave w = waves[wave];
+    const int G = w.G;
+    const int grp = lane / G;
+    const int gl = lane - grp * G;
+    const bool active = grp < (int)w.n_groups;
+    const bool start = gl == 0;
+
+    PhGroup g;
+    g.hap_dw = g.H = g.R_tab = g.out = 0;
+    g.init64 = 0;
+    g.init32 = 0;
+    if (active) g = groups[w.first_group + grp];
+    const int R = (int)(g.R_tab & 0xffffu);
+    const int H = (int)g.H;
+
+    bool wanted = active;
+    if constexpr (RESCUE) {
+        // second pass over an fp32 result: only pairs that underflowed are recomputed in double
+        const double prev = active ? sums[g.out] : 1.0;
+        wanted = active && !(prev >= rescue_below);
+        if (!__any(wanted)) return;
+    }
+
+    // ---- read tables -> LDS
+    const uint32_t rows = w.steps + (uint32_t)G - 1u;
+    const size_t tab_bytes = ph_tab_bytes(sizeof(T) == 8, rows);
+    for (uint32_t k = 0; k < w.n_tabs; ++k) {
+        const PhTab tb = tabs[w.first_tab + k];
+        T *tq = reinterpret_cast<T *>(lds + k * tab_bytes);
+        unsigned char *tc = reinterpret_cast<unsigned char *>(tq + 4 * rows);
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
+        const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
+        for (uint32_t r = lane; r < rows; r += 64) {
+            const int i = (int)r - (G - 1);
+            T vr = 0, vi = 0, vd = 0, vg = 1; // neutral row
+            unsigned char c = 0;
+            if (i >= 0 && i < (int)tb.R) {
+                if constexpr (PROBS) { // pairHMM() seam: tracks are probabilities, bases follow them
+                    const double *q = reinterpret_cast<const double *>(rp);
+                    vr = (T)q[i];
+                    vi = (T)q[tb.R + i];
+                    vd = (T)q[2 * tb.R + i];
+                    vg = (T)q[3 * tb.R + i];
+                    c = reinterpret_cast<const unsigned char *>(q + 4 * tb.R)[i];
+                } else {
+                    c = rp[i];
+                    vr = lut[rp[trk + i]];
+                    vi = lut[rp[2 * trk + i]];
+                    vd = lut[rp[3 * trk + i]];
+                    vg = lut[rp[4 * trk + i]];
+                }
+            }
+            tq[r] = vr;
+            tq[rows + r] = vi;
+            tq[2 * rows + r] = vd;
+            tq[3 * rows + r] = vg;
+            tc[r] = c;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t tabi = g.R_tab >> 16;
+    const T *tq = reinterpret_cast<const T *>(lds + tabi * tab_bytes) + (G - 1 - gl);
+    const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + 4 * rows * sizeof(T)) + (G - 1 - gl);
+
+    uint32_t hw[HW];
+#pragma unroll
+    for (int k = 0; k < HW; ++k) hw[k] = active ? img[g.hap_dw + gl * HW + k] : 0u;
+    bool hn[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) hn[j] = ((hw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N';
+
+    const T init = sizeof(T) == 8 ? (T)g.init64 : (T)g.init32;
+    T M[C], X[C], Y[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        M[j] = 0;
+        X[j] = 0;
+        Y[j] = init;
+    }
+    T pM = 0, pX = 0, pY = init; // what arrived from the left one step ago = diagonal neighbour
+    T acc_prev = 0, result = 0;
+    const int steps = (int)w.steps;
+    const int col0 = gl * C;
+
+    for (int t = 0; t < steps; ++t) {
+        const T q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
+        const uint32_t rc = tc[t];
+        const T pm = 1 - q_r;                          // p(): match or N (:111-113)
+        const T pq = rc == (uint32_t)'N' ? pm : q_r;   //      mismatch
+        const T mm = 1 - (q_i + q_d);                  // mm() (:115-117)
+        const T gm = 1 - q_g;
+
+        T lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
+        T acc = shr1(acc_prev);
+        if (start) { // column 0 of rows >= 1 (:168-178)
+            lM = 0;
+            lX = 0;
+            lY = 0;
+            acc = 0;
+        }
+        T dM = pM, dX = pX, dY = pY;
+        pM = lM;
+        pX = lX;
+        pY = lY;
+        T cM = lM, cY = lY;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const uint32_t hc = (hw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            const T oM = M[j], oX = X[j], oY = Y[j];
+            const T prior = (hc == rc || hn[j]) ? pm : pq;
+            const T m = prior * mad<FMA>(mm, dM, gm * (dX + dY)); // :184
+            const T x = mad<FMA>(oM, q_i, oX * q_g);               // :189
+            const T y = mad<FMA>(cM, q_d, cY * q_g);               // :194
+            M[j] = m;
+            X[j] = x;
+            Y[j] = y;
+            dM = oM;
+            dX = oX;
+            dY = oY;
+            cM = m;
+            cY = y;
+        }
+        if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+#pragma unroll
+            for (int j = 0; j < C; ++j)
+                if (col0 + j < H) acc += (M[j] + X[j]);
+            if (gl == G - 1) result = acc;
+        }
+        acc_prev = acc;
+    }
+
+    if (wanted && gl == G - 1) {
+        // the rescue pass stores its (double-scaled) sum negated so the host can tell the scalings apart
+        sums[g.out] = RESCUE ? -(double)result : (double)result;
+        if constexpr (RESCUE) atomicAdd(n_rescued, 1ull);
+    }
+}
+
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
+           const void *lut, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds, hipStream_t s)
+{
+    auto k = phmm_fill<T, C, FMA, RESCUE, PROBS>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -1;
+    }
+    hipLaunchKernelGGL(k, dim3(n_waves), dim3(64), lds, s, img, groups, tabs, waves, n_waves, (const T *)lut, sums,
+                       rescue_below, n_rescued);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int C>
+int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+                uint32_t n_waves, const void *lut, double *sums, double rescue_below, unsigned long long *n_rescued,
+                size_t lds, hipStream_t s)
+{
+    switch (mode) {
+    case 0: return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    case 1: return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    case 2: return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    case 3: return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    case 4: return launch<double, C, false, false, true>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    default: return -2;
+    }
+}
+
+} // namespace
+
+int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
+                          const PhWave *waves, uint32_t n_waves, const void *lut, double *sums, double rescue_below,
+                          unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+#define AGX_PH_CASE(CC) \
+    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds_bytes, s)
+    switch (cols_per_lane) {
+        AGX_PH_CASE(4);
+        AGX_PH_CASE(8);
+        AGX_PH_CASE(12);
+        AGX_PH_CASE(16);
+        AGX_PH_CASE(24);
+        AGX_PH_CASE(32);
+    default: return -2;
+    }
+#undef AGX_PH_CASE
+}

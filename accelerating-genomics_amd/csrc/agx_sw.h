@@ -1,0 +1,31 @@
+// Device work records of the Smith-Waterman fill (shared by scheduler and kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// One alignment pair = one group of G lanes.  Offsets are in 4-byte words into the packed
+// image: x (the shorter sequence, zero-padded to G*C bytes), y (the longer, padded to 4).
+struct SwGroup {
+    uint32_t x_dw;
+    uint32_t y_dw;
+    uint32_t lx_ly; // lx | ly << 16
+    uint32_t out;   // index into scores[]
+};
+
+// One wavefront: n_groups groups of G lanes, all stepping `steps` rows (multiple of 4,
+// >= max(ly) + G - 1 over its groups).
+struct SwWave {
+    uint32_t first_group;
+    uint16_t n_groups;
+    uint16_t G;
+    uint32_t steps;
+    uint32_t reserved;
+};
+
+// Column-per-lane classes the kernel is instantiated for.
+static const int kSwClasses[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40};
+static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
+
+int agx_sw_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup *groups, const SwWave *waves,
+                        uint32_t n_waves, int32_t *scores, hipStream_t s);

@@ -1,0 +1,280 @@
+/*
+ * Readers for the reference's two text formats (include/agx.h, "text front end").
+ * Plain C99; no device code.  They restate the reading rules of
+ *   smithWaterman/antidiagonalSmithWaterman.c:201-247  and
+ *   pairHMM/antidiagsPairHMM.c:353-418,484-489
+ * so the drop-in command lines see exactly the pairs the reference programs see.
+ */
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "agx.h"
+
+/* implemented in agx_runtime.cpp */
+extern void agx_set_error(const char *fmt, ...);
+
+/* ------------------------------------------------------------ growable byte/array helpers */
+
+typedef struct {
+    unsigned char *p;
+    size_t n, cap;
+} buf_t;
+
+static int buf_reserve(buf_t *b, size_t extra)
+{
+    if (b->n + extra <= b->cap) return 0;
+    size_t cap = b->cap ? b->cap : 4096;
+    while (cap < b->n + extra) cap *= 2;
+    unsigned char *q = (unsigned char *)realloc(b->p, cap);
+    if (!q) return -1;
+    b->p = q;
+    b->cap = cap;
+    return 0;
+}
+
+static int buf_put(buf_t *b, const void *src, size_t n)
+{
+    if (buf_reserve(b, n ? n : 1)) return -1;
+    if (n) memcpy(b->p + b->n, src, n);
+    b->n += n;
+    return 0;
+}
+
+/* -------------------------------------------------------------------------- Smith-Waterman */
+
+void agx_sw_text_free(agx_sw_text *t)
+{
+    if (!t) return;
+    free(t->bases);
+    free(t->off);
+    free(t->len);
+    free(t->dangling);
+    free(t);
+}
+
+int agx_sw_text_read(const char *path, int line_buf, agx_sw_text **out)
+{
+    if (!out || !path) {
+        agx_set_error("agx_sw_text_read: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
+    if (line_buf <= 0) line_buf = 1000; /* MAX_LINE_LENGTH, antidiagonalSmithWaterman.c:44 */
+    if (line_buf < 2) {
+        agx_set_error("agx_sw_text_read: line buffer too small");
+        return AGX_E_ARG;
+    }
+    FILE *f = fopen(path, "r");
+    if (!f) {
+        agx_set_error("Error opening file: %s", strerror(errno));
+        return AGX_E_IO;
+    }
+    int rc = AGX_E_NOMEM;
+    char *l1 = (char *)malloc((size_t)line_buf), *l2 = (char *)malloc((size_t)line_buf);
+    agx_sw_text *t = (agx_sw_text *)calloc(1, sizeof *t);
+    buf_t bases = {0}, off = {0}, len = {0};
+    if (!l1 || !l2 || !t) goto done;
+    if (!fgets(l1, line_buf, f)) { /* ":205-208" file is empty */
+        agx_set_error("file is empty");
+        rc = AGX_E_IO;
+        t->line_num = -1;
+        goto done;
+    }
+    t->line_num = atoi(l1); /* number of sequence LINES, :209 */
+    for (int i = 0; i < t->line_num; i += 2) {
+        if (!fgets(l1, line_buf, f)) break; /* :219-221 */
+        if (!fgets(l2, line_buf, f)) {      /* :223-227: the first line is echoed, loop ends */
+            t->dangling = strdup(l1);
+            if (!t->dangling) goto done;
+            break;
+        }
+        const char *s[2] = {l1, l2};
+        for (int k = 0; k < 2; k++) {
+            uint64_t o = bases.n;
+            uint32_t n = (uint32_t)strlen(s[k]); /* newline included, :229-247 */
+            if (buf_put(&bases, s[k], n) || buf_put(&off, &o, sizeof o) || buf_put(&len, &n, sizeof n)) goto done;
+        }
+        t->n_pairs++;
+    }
+    t->bases = bases.p;
+    t->off = (uint64_t *)off.p;
+    t->len = (uint32_t *)len.p;
+    bases.p = off.p = len.p = NULL;
+    rc = AGX_OK;
+done:
+    fclose(f);
+    free(l1);
+    free(l2);
+    free(bases.p);
+    free(off.p);
+    free(len.p);
+    if (rc == AGX_E_NOMEM) agx_set_error("agx_sw_text_read: out of memory");
+    if (rc != AGX_OK) {
+        agx_sw_text_free(t);
+        t = NULL;
+    }
+    *out = t;
+    return rc;
+}
+
+/* --------------------------------------------------------------------------------- PairHMM */
+
+typedef struct {
+    agx_phmm_text pub; /* must be first */
+    buf_t rb, qb, qi, qd, qg, roff, hb, hoff, rreg, hreg;
+} phmm_text_impl;
+
+void agx_phmm_text_free(agx_phmm_text *t)
+{
+    if (!t) return;
+    phmm_text_impl *m = (phmm_text_impl *)t;
+    free(m->rb.p);
+    free(m->qb.p);
+    free(m->qi.p);
+    free(m->qd.p);
+    free(m->qg.p);
+    free(m->roff.p);
+    free(m->hb.p);
+    free(m->hoff.p);
+    free(m->rreg.p);
+    free(m->hreg.p);
+    free(m);
+}
+
+#define PHMM_LINE (1000 * 5 + 1) /* MAX_READ_LEN*5+1, antidiagsPairHMM.c:8,353 */
+
+/* next whitespace-delimited token of s (sscanf "%s" rule); returns its length, *tok its start */
+static size_t next_token(const char **s, const char **tok)
+{
+    const char *p = *s;
+    while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r') p++;
+    *tok = p;
+    while (*p && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) p++;
+    *s = p;
+    return (size_t)(p - *tok);
+}
+
+int agx_phmm_text_read(const char *path, agx_phmm_text **out)
+{
+    if (!out || !path) {
+        agx_set_error("agx_phmm_text_read: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
+    FILE *f = fopen(path, "r");
+    if (!f) {
+        agx_set_error("Error opening input file_r: %s", strerror(errno));
+        return AGX_E_IO;
+    }
+    int rc = AGX_E_NOMEM;
+    phmm_text_impl *m = (phmm_text_impl *)calloc(1, sizeof *m);
+    char *line = (char *)malloc(PHMM_LINE);
+    char **rl = NULL;
+    int nr = 0, nh = 0; /* sscanf leaves them untouched on a malformed header (:378) */
+    uint64_t z64 = 0;
+    uint32_t z32 = 0;
+    if (!m || !line) goto done;
+    if (buf_put(&m->roff, &z64, 8) || buf_put(&m->hoff, &z64, 8) || buf_put(&m->rreg, &z32, 4) || buf_put(&m->hreg, &z32, 4)) goto done;
+    uint32_t n_reads = 0, n_haps = 0, n_regions = 0;
+    while (fgets(line, PHMM_LINE, f)) { /* :375 */
+        m->pub.n_regions_seen++;
+        sscanf(line, "%d %d", &nr, &nh);
+        if (nr < 0) nr = 0;
+        if (nh < 0) nh = 0;
+        /* the reference reads the haplotypes first through a second stream (:389-407) and fails
+         * with "Error reading haplotypes." when the region is cut short: nothing of it is output */
+        rl = (char **)calloc((size_t)nr + 1, sizeof(char *));
+        if (!rl) goto done;
+        int got_r = 0, got_h = 0, bad = 0;
+        for (; got_r < nr; got_r++) {
+            if (!fgets(line, PHMM_LINE, f)) break;
+            line[strcspn(line, "\n")] = 0; /* :417 */
+            rl[got_r] = strdup(line);
+            if (!rl[got_r]) goto done;
+        }
+        const size_t hb_mark = m->hb.n, hoff_mark = m->hoff.n;
+        if (got_r == nr) {
+            for (; got_h < nh; got_h++) {
+                if (!fgets(line, PHMM_LINE, f)) break;
+                line[strcspn(line, "\n")] = 0; /* :399 */
+                size_t n = strlen(line);
+                if (buf_put(&m->hb, line, n)) goto done;
+                uint64_t o = m->hb.n;
+                if (buf_put(&m->hoff, &o, 8)) goto done;
+            }
+        }
+        if (got_r < nr || got_h < nh) {
+            m->hb.n = hb_mark;
+            m->hoff.n = hoff_mark;
+            m->pub.truncated = 1;
+            bad = 1;
+        }
+        const size_t rb_mark = m->rb.n, roff_mark = m->roff.n;
+        for (int i = 0; i < nr && !bad; i++) {
+            size_t sl = strlen(rl[i]);
+            if (sl < 4) { /* (strlen-4)/5 underflows in the reference (:418) */
+                agx_set_error("region %u, read %d: line too short to hold five fields", n_regions + 1, i);
+                rc = AGX_E_IO;
+                goto done;
+            }
+            size_t n = (sl - 4) / 5;
+            const char *p = rl[i], *tok[5];
+            size_t tl[5];
+            for (int k = 0; k < 5; k++) tl[k] = next_token(&p, &tok[k]);
+            for (int k = 0; k < 5; k++)
+                if (tl[k] < n) {
+                    agx_set_error("region %u, read %d: field %d shorter than the read length %zu", n_regions + 1, i, k, n);
+                    rc = AGX_E_IO;
+                    goto done;
+                }
+            if (buf_put(&m->rb, tok[0], n) || buf_put(&m->qb, tok[1], n) || buf_put(&m->qi, tok[2], n) ||
+                buf_put(&m->qd, tok[3], n) || buf_put(&m->qg, tok[4], n))
+                goto done;
+            uint64_t o = m->rb.n;
+            if (buf_put(&m->roff, &o, 8)) goto done;
+        }
+        for (int i = 0; i < nr; i++) free(rl[i]);
+        free(rl);
+        rl = NULL;
+        if (bad) {
+            m->rb.n = m->qb.n = m->qi.n = m->qd.n = m->qg.n = rb_mark;
+            m->roff.n = roff_mark;
+            break;
+        }
+        n_reads += (uint32_t)nr;
+        n_haps += (uint32_t)nh;
+        n_regions++;
+        if (buf_put(&m->rreg, &n_reads, 4) || buf_put(&m->hreg, &n_haps, 4)) goto done;
+        m->pub.n_pairs += (int64_t)nr * nh;
+    }
+    m->pub.desc.read_bases = m->rb.p;
+    m->pub.desc.q_base = m->qb.p;
+    m->pub.desc.q_ins = m->qi.p;
+    m->pub.desc.q_del = m->qd.p;
+    m->pub.desc.q_gcp = m->qg.p;
+    m->pub.desc.read_off = (const uint64_t *)m->roff.p;
+    m->pub.desc.n_reads = n_reads;
+    m->pub.desc.hap_bases = m->hb.p;
+    m->pub.desc.hap_off = (const uint64_t *)m->hoff.p;
+    m->pub.desc.n_haps = n_haps;
+    m->pub.desc.region_read = (const uint32_t *)m->rreg.p;
+    m->pub.desc.region_hap = (const uint32_t *)m->hreg.p;
+    m->pub.desc.n_regions = n_regions;
+    rc = AGX_OK;
+done:
+    fclose(f);
+    free(line);
+    if (rl) {
+        for (int i = 0; i < nr; i++) free(rl[i]);
+        free(rl);
+    }
+    if (rc == AGX_E_NOMEM) agx_set_error("agx_phmm_text_read: out of memory");
+    if (rc != AGX_OK) {
+        agx_phmm_text_free(m ? &m->pub : NULL);
+        m = NULL;
+    }
+    *out = m ? &m->pub : NULL;
+    return rc;
+}

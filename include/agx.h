@@ -1,0 +1,216 @@
+/*
+ * agx.h -- C-ABI of libagx.so: the MI355X (gfx950) drop-in for the two
+ * anti-diagonal DP hot paths of AnteMarusic/Accelerating-Genomics:
+ *
+ *   - Smith-Waterman affine-gap score-only fill
+ *       replaces the per-pair loop body of smithWaterman/antidiagonalSmithWaterman.c:254-348
+ *       (and the kernel launch of smithWaterman/hipvers.cpp:470-483)
+ *   - PairHMM forward recurrence
+ *       replaces pairHMM() of pairHMM/antidiagsPairHMM.c:120-267 (fp64 semantics of
+ *       pairHMM/pairHMMmatrix.c:41-66) as called from the batch loop :411-461
+ *
+ * The reference exposes no library API: its surface is two command lines and
+ * one function seam.  This header is what a C host binds
+ * instead; the drop-in command lines in accelerating-genomics_amd/host/ are
+ * built on exactly these entry points.  Plain C99, plain pointers and sizes,
+ * caller-owned buffers, int status (0 = AGX_OK, < 0 = error, text via
+ * agx_last_error()).  A context and everything created from it belong to one
+ * host thread at a time; distinct contexts may be used from distinct threads.
+ *
+ * There is no CPU fallback: every compute entry point fails with
+ * AGX_E_NODEVICE when no HIP device is usable.
+ */
+#ifndef AGX_H
+#define AGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGX_OK 0
+#define AGX_E_ARG (-1)      /* bad argument (NULL pointer, negative count, inconsistent offsets) */
+#define AGX_E_NODEVICE (-2) /* no usable HIP device / ordinal out of range */
+#define AGX_E_HIP (-3)      /* a HIP runtime call failed; agx_last_error() has the HIP text */
+#define AGX_E_NOMEM (-4)    /* host or device allocation failed */
+#define AGX_E_SYMBOL (-5)   /* a sequence contains byte 0x00, reserved as the padding symbol */
+#define AGX_E_LIMIT (-6)    /* a length exceeds what the kernels support (see AGX_*_MAX_*) */
+#define AGX_E_IO (-7)       /* parser: file cannot be opened / is malformed */
+
+/* Smith-Waterman: the shorter sequence of a pair is laid across lanes, at most
+ * 64 lanes x AGX_SW_MAX_COLS_PER_LANE columns; the longer one streams.  (The
+ * reference CLI cannot produce lines of 1000 bytes or more,
+ * antidiagonalSmithWaterman.c:44; hipvers.cpp:40 allows 10000.) */
+#define AGX_SW_MAX_COLS_PER_LANE 40
+#define AGX_SW_MAX_SHORT_LEN (64 * AGX_SW_MAX_COLS_PER_LANE)
+/* PairHMM: haplotype across lanes (64 x AGX_PHMM_MAX_COLS_PER_LANE), read streams. */
+#define AGX_PHMM_MAX_COLS_PER_LANE 32
+#define AGX_PHMM_MAX_HAP_LEN (64 * AGX_PHMM_MAX_COLS_PER_LANE)
+#define AGX_PHMM_MAX_READ_LEN 4096
+
+/* ------------------------------------------------------------------ runtime */
+
+typedef struct agx_ctx agx_ctx; /* one device + one HIP stream + reusable workspaces */
+
+const char *agx_version(void);
+const char *agx_last_error(void); /* thread-local, never NULL */
+int agx_device_count(void);       /* >= 0; 0 when HIP reports no device */
+
+int agx_ctx_create(int device, agx_ctx **out);
+void agx_ctx_destroy(agx_ctx *ctx);
+int agx_ctx_device(const agx_ctx *ctx);
+/* The hipStream_t all launches of this context go to (as void*).  A host that
+ * already owns a stream (e.g. PyTorch's current stream) may install it. */
+void *agx_ctx_stream(const agx_ctx *ctx);
+int agx_ctx_set_stream(agx_ctx *ctx, void *hip_stream);
+int agx_ctx_sync(agx_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (used by bench.py for the roofline figures). */
+int agx_ctx_timer_start(agx_ctx *ctx);
+int agx_ctx_timer_stop(agx_ctx *ctx, float *elapsed_ms);
+
+/* ----------------------------------------------------------- Smith-Waterman */
+
+/*
+ * Input layout (host memory): sequence k is bases[off[k] .. off[k]+len[k]);
+ * pair p aligns sequences 2p and 2p+1 -- the file order of
+ * antidiagonalSmithWaterman.c:216-227.  Sequences are raw symbols: the caller
+ * decides whether a trailing '\n' belongs to them (the reference CLI keeps it,
+ * antidiagonalSmithWaterman.c:229-247; agx_sw_text does the same).  Scoring is
+ * the reference's compile-time constants (:40-43): match +1, mismatch -1,
+ * gap open -3, gap extend -1.  scores[p] = max over the matrix, >= 0, int32,
+ * bit-exact with the reference.
+ */
+typedef struct agx_sw_batch agx_sw_batch; /* a scheduled batch resident in HBM */
+
+typedef struct agx_sw_info {
+    int64_t n_pairs;
+    int64_t cells;        /* sum len_a*len_b over pairs, as given (sentinels included) */
+    int64_t padded_cells; /* lane-steps x columns actually issued (>= cells) */
+    int64_t input_bytes;  /* bytes of the packed device image the kernels read */
+    int32_t n_launches;   /* kernel launches per agx_sw_batch_launch() */
+    int32_t n_waves;      /* wavefronts over all launches */
+} agx_sw_info;
+
+/* Validate, pick the lane tiling per pair, pack and copy to the device.  Blocking. */
+int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
+                        int64_t n_pairs, agx_sw_batch **out);
+/* Enqueue the fill on the context's stream; scores stay in HBM.  Asynchronous. */
+int agx_sw_batch_launch(agx_sw_batch *b);
+/* Wait for the stream and copy the scores out in the caller's pair order. */
+int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores);
+int agx_sw_batch_info(const agx_sw_batch *b, agx_sw_info *info);
+void agx_sw_batch_destroy(agx_sw_batch *b);
+
+/* One-shot: create + launch + scores + destroy. */
+int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
+                 int32_t *scores);
+/* Same, sharded by cells over `n_devices` devices (<= 0: all visible), one host
+ * thread and context per device, no collective. */
+int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
+                       int64_t n_pairs, int32_t *scores);
+
+/* ------------------------------------------------------------------ PairHMM */
+
+/*
+ * Input layout (host memory), mirroring the reference's regions ("batches",
+ * antidiagsPairHMM.c:371-461): read r has length read_off[r+1]-read_off[r]
+ * and five byte tracks at that offset (bases, base/insertion/deletion/gcp
+ * qualities, Phred+33 characters exactly as in the text file); haplotype h is
+ * hap_bases[hap_off[h] .. hap_off[h+1]).  Region g pairs reads
+ * [region_read[g], region_read[g+1]) with haplotypes
+ * [region_hap[g], region_hap[g+1]).  Results are written region by region,
+ * read-major, haplotype-minor -- the order of the reference's output file.
+ */
+typedef struct agx_phmm_desc {
+    const uint8_t *read_bases, *q_base, *q_ins, *q_del, *q_gcp;
+    const uint64_t *read_off; /* n_reads + 1 */
+    uint32_t n_reads;
+    const uint8_t *hap_bases;
+    const uint64_t *hap_off; /* n_haps + 1 */
+    uint32_t n_haps;
+    const uint32_t *region_read; /* n_regions + 1 */
+    const uint32_t *region_hap;  /* n_regions + 1 */
+    uint32_t n_regions;
+} agx_phmm_desc;
+
+/* Arithmetic of the recurrence. */
+#define AGX_PHMM_F64 0      /* double, reference expression order, no FMA contraction:
+                               the raw sum is bit-identical to pairHMMmatrix.c */
+#define AGX_PHMM_F64_FMA 1  /* double with FMA contraction (<= 1e-12 relative on log10) */
+#define AGX_PHMM_F32 2      /* float with initial constant FLT_MAX/16 (BASELINE config 3);
+                               pairs whose float sum falls below AGX_PHMM_F32_RESCUE are
+                               recomputed with AGX_PHMM_F64 on the device */
+#define AGX_PHMM_F32_RESCUE 1e-28f
+
+typedef struct agx_phmm_batch agx_phmm_batch;
+
+typedef struct agx_phmm_info {
+    int64_t n_pairs;
+    int64_t cells;        /* sum R*H */
+    int64_t padded_cells; /* lane-steps x columns issued */
+    int64_t input_bytes;
+    int32_t n_launches;
+    int32_t n_waves;
+    int64_t n_rescued;    /* F32 only: pairs recomputed in double by the last launch+results */
+} agx_phmm_info;
+
+int agx_phmm_batch_create(agx_ctx *ctx, const agx_phmm_desc *d, int precision, agx_phmm_batch **out);
+int agx_phmm_batch_launch(agx_phmm_batch *b);
+/* log10_lik[k] = log10(sum_k) - log10(C), C = DBL_MAX/16 (FLT_MAX/16 for F32), both log10 taken by the
+ * host libm in double exactly as antidiagsPairHMM.c:242; raw_sum (may be NULL) receives sum_k. */
+int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum);
+int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info);
+void agx_phmm_batch_destroy(agx_phmm_batch *b);
+
+int agx_phmm_forward(agx_ctx *ctx, const agx_phmm_desc *d, int precision, double *log10_lik);
+int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik);
+
+/*
+ * The reference's only function-level seam, same argument list as
+ * antidiagsPairHMM.c:120 (M/X/Y scratch is accepted and ignored; *likelihood is
+ * overwritten with the log10 value, i.e. started from 0 -- SURVEY.md Q8).
+ * Qr/Qi/Qd/Qg are probabilities, not Phred characters.  Runs one pair on
+ * device 0 through a process-wide lazily created context; returns nothing, as
+ * the reference does: on failure *likelihood = NaN and agx_last_error() is set.
+ */
+void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, char *H, int read_len,
+                 int haplotype_len, double *Qr, double *Qi, double *Qd, double *Qg);
+
+/* ------------------------------------------------------------- text front end */
+
+/*
+ * Readers for the reference's two input formats, producing the flat layouts
+ * above (n1 in SURVEY.md 8f).  They follow the reference's reading rules,
+ * including its quirks: SW header = number of sequence LINES, fgets with a
+ * 1000-byte buffer (longer lines split), newline kept as a symbol, loop ends
+ * at the first missing line (antidiagonalSmithWaterman.c:201-227); PairHMM
+ * read length = (strlen(line)-4)/5 (antidiagsPairHMM.c:418).
+ */
+typedef struct agx_sw_text {
+    int32_t line_num;   /* header value as atoi() reads it */
+    int64_t n_pairs;    /* pairs the reference loop would score */
+    uint8_t *bases;
+    uint64_t *off;      /* 2*n_pairs */
+    uint32_t *len;      /* 2*n_pairs */
+    char *dangling;     /* first line of an unpaired trailing pair (the reference echoes it, :225) or NULL */
+} agx_sw_text;
+
+int agx_sw_text_read(const char *path, int line_buf /* 0 = reference's 1000 */, agx_sw_text **out);
+void agx_sw_text_free(agx_sw_text *t);
+
+typedef struct agx_phmm_text {
+    agx_phmm_desc desc; /* points into storage owned by this object */
+    int64_t n_pairs;
+    int32_t n_regions_seen; /* header lines read, for the "#batch:" chatter */
+    int32_t truncated;      /* 1 = a region ended early (the reference exits with failure there) */
+} agx_phmm_text;
+
+int agx_phmm_text_read(const char *path, agx_phmm_text **out);
+void agx_phmm_text_free(agx_phmm_text *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGX_H */

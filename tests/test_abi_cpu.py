@@ -1,0 +1,103 @@
+"""CPU-side checks of the product boundary: libagx.so loads, exports every symbol include/agx.h
+declares, refuses to compute without a device (no fallback), and its text readers see exactly
+the pairs the reference programs see (checked by scoring them with the oracle against the goldens)."""
+import ctypes
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import accelerating_genomics_amd.api as agx
+import accelerating_genomics_amd.synth as synth
+from tests.test_oracle_sw import expect_scores
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(agx.LIB_PATH):
+        agx.build()
+
+
+def test_header_and_library_agree_on_symbols():
+    hdr = open(os.path.join(ROOT, "include", "agx.h")).read()
+    declared = set(re.findall(r"\b(agx_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert declared == set(agx.SYMBOLS)
+    lib = ctypes.CDLL(agx.LIB_PATH)
+    for s in agx.SYMBOLS:
+        assert hasattr(lib, s), s
+
+
+def test_no_device_means_loud_failure_not_fallback():
+    if agx.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(agx.AgxError) as e:
+        agx.Context(0)
+    assert e.value.code == agx.E_NODEVICE
+    b = synth.sw_pairs(2, 5, 9, seed=1)
+    with pytest.raises(agx.AgxError) as e:
+        agx.sw_score_multi(b)
+    assert e.value.code == agx.E_NODEVICE
+    with pytest.raises(agx.AgxError):
+        agx.phmm_forward_multi(synth.phmm_regions(1, 1, 1, 5, 9, seed=1))
+
+
+def test_product_never_touches_the_oracle():
+    for path in glob.glob(os.path.join(ROOT, "accelerating-genomics_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".c", ".cpp", ".h", ".hip", "Makefile")):
+            txt = open(path, errors="replace").read()
+            assert "liboracle" not in txt and "oracle_api" not in txt and "oracle/" not in txt, path
+
+
+SW_CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "sw_*.in")))
+
+
+@pytest.mark.parametrize("name", SW_CASES)
+def test_sw_text_reader_sees_the_reference_pairs(oracle, golden_dir, name):
+    n_ref, s_ref = expect_scores(os.path.join(golden_dir, name + ".expect"))
+    line_num, b, dangling = agx.read_sw_text(os.path.join(golden_dir, name + ".in"))
+    assert line_num == n_ref and b.n_pairs == s_ref.size
+    assert np.array_equal(oracle.sw_batch(b), s_ref)
+    if name == "sw_oddlines":
+        assert dangling is not None and open(os.path.join(golden_dir, name + ".expect"), "rb").read().endswith(dangling)
+    else:
+        assert dangling is None
+
+
+def test_sw_text_reader_splits_long_lines_like_fgets(tmp_path, oracle):
+    p = tmp_path / "long.in"
+    p.write_bytes(b"2\n" + b"A" * 1500 + b"\n" + b"C" * 10 + b"\n")
+    _, b, _ = agx.read_sw_text(str(p))  # 1000-byte buffer: 999 + 501+'\n' become the pair, 'C...' is never read
+    assert b.n_pairs == 1 and list(b.len) == [999, 502]
+    _, b, _ = agx.read_sw_text(str(p), 10000)  # hipvers.cpp:40 buffer
+    assert list(b.len) == [1501, 11]
+
+
+def test_sw_text_reader_errors(tmp_path):
+    with pytest.raises(agx.AgxError) as e:
+        agx.read_sw_text(str(tmp_path / "missing"))
+    assert e.value.code == agx.E_IO
+    (tmp_path / "empty").write_bytes(b"")
+    with pytest.raises(agx.AgxError) as e:
+        agx.read_sw_text(str(tmp_path / "empty"))
+    assert "file is empty" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"])
+def test_phmm_text_reader_matches_python_mirror(golden_dir, name):
+    path = os.path.join(golden_dir, name + ".in")
+    got, seen, trunc = agx.read_phmm_text(path)
+    want = synth.parse_phmm_text(open(path, "rb").read())
+    assert trunc == 0 and seen == want.n_regions
+    for f in ("read_bases", "q_base", "q_ins", "q_del", "q_gcp", "roff", "hap_bases", "hoff", "rreg", "hreg"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+
+
+def test_phmm_text_reader_truncated_region(tmp_path, golden_dir):
+    data = open(os.path.join(golden_dir, "phmm_synth.in"), "rb").read().split(b"\n")
+    (tmp_path / "cut.in").write_bytes(b"\n".join(data[:14]) + b"\n")  # region 1 = 1+6+4 lines, region 2 cut short
+    got, seen, trunc = agx.read_phmm_text(str(tmp_path / "cut.in"))
+    assert trunc == 1 and seen == 2 and got.n_regions == 1 and got.n_pairs == 24

@@ -1,0 +1,109 @@
+"""GPU parity of the Smith-Waterman fill (through the C-ABI) against the oracle and the
+reference's golden outputs.  Bar: bit-exact int32 scores."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import accelerating_genomics_amd.api as agx
+import accelerating_genomics_amd.synth as synth
+from tests.test_oracle_sw import expect_scores
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with agx.Context(0) as c:
+        yield c
+
+
+GOLD = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sw_*.in")))
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_golden_files_bit_exact(ctx, golden_dir, name):
+    """text reader + kernel vs stdout of the unmodified reference program."""
+    n_ref, s_ref = expect_scores(os.path.join(golden_dir, name + ".expect"))
+    line_num, b, _ = agx.read_sw_text(os.path.join(golden_dir, name + ".in"))
+    assert line_num == n_ref
+    assert np.array_equal(ctx.sw_score(b), s_ref)
+
+
+@pytest.mark.parametrize("lo,hi,n,seed", [(1, 8, 500, 1), (1, 70, 2000, 2), (150, 150, 1024, 3), (32, 512, 1500, 4),
+                                          (500, 999, 64, 5), (1000, 2500, 6, 6)])
+def test_random_and_related_pairs_vs_oracle(ctx, oracle, lo, hi, n, seed):
+    b = synth.sw_pairs(n, lo, hi, seed=seed, related_frac=0.5)
+    assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b))
+
+
+def test_every_short_length_and_tiling_boundary(ctx, oracle):
+    """lx = 1..170 against ly in {lx, lx+1, 3*lx}: walks every (C, G) choice incl. non-power-of-two G."""
+    rng = np.random.default_rng(7)
+    seqs = []
+    for lx in range(1, 171):
+        for ly in (lx, lx + 1, 3 * lx):
+            a = b"ACGT"[0:0] + bytes(rng.choice(list(b"ACGT"), size=lx).tolist())
+            y = bytearray(rng.choice(list(b"ACGT"), size=ly).tolist())
+            st = int(rng.integers(0, ly - lx + 1))
+            y[st : st + lx] = a  # embed a copy so the optimum is a long diagonal
+            if lx > 4:
+                y[st + lx // 2] = ord("N")
+            seqs += [a, bytes(y)]
+    b = synth.sw_from_seqs(seqs)
+    assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b))
+
+
+def test_empty_and_degenerate(ctx, oracle):
+    b = synth.sw_from_seqs([b"", b"ACGT", b"ACGT", b"", b"", b"", b"A", b"A", b"\n", b"\n", b"A\n", b"C\n"])
+    got = ctx.sw_score(b)
+    assert np.array_equal(got, oracle.sw_batch(b))
+    assert list(got) == [0, 0, 0, 1, 1, 1]
+    assert ctx.sw_score(synth.sw_from_seqs([])).size == 0
+
+
+def test_all_byte_values_are_symbols(ctx, oracle):
+    rng = np.random.default_rng(11)
+    seqs = [bytes(rng.integers(1, 256, size=int(rng.integers(1, 300))).astype(np.uint8).tolist()) for _ in range(400)]
+    for k in range(0, 400, 4):  # make some pairs related
+        seqs[k + 1] = seqs[k][3:] + seqs[k + 1][:5]
+    b = synth.sw_from_seqs(seqs)
+    assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b))
+
+
+def test_reserved_symbol_and_limits_fail_loudly(ctx):
+    with pytest.raises(agx.AgxError) as e:
+        ctx.sw_score(synth.sw_from_seqs([b"AC\x00GT", b"ACGT"]))
+    assert e.value.code == agx.E_SYMBOL
+    with pytest.raises(agx.AgxError) as e:
+        ctx.sw_score(synth.sw_from_seqs([b"A" * 3000, b"C" * 3000]))
+    assert e.value.code == agx.E_LIMIT
+
+
+def test_batch_object_relaunch_is_idempotent(ctx, oracle):
+    b = synth.sw_pairs(3000, 100, 200, seed=9, related_frac=0.3)
+    dev = ctx.sw_batch(b)
+    dev.launch()
+    first = dev.scores()
+    for _ in range(3):
+        dev.launch()
+    assert np.array_equal(dev.scores(), first)
+    assert np.array_equal(first, oracle.sw_batch(b))
+    info = dev.info()
+    assert info.n_pairs == 3000 and info.cells == b.cells() and info.padded_cells >= info.cells
+    dev.close()
+
+
+def test_full_size_config2_properties(ctx, oracle):
+    """BASELINE config 2 at full size (65 536 pairs, 150x150): too big for the scalar oracle in
+    seconds, so check (a) a 2 048-pair sample against it, (b) score(a,b) == score(b,a),
+    (c) identical pairs score len+1 (the '\\n' sentinel matches too)."""
+    b = synth.sw_pairs(65536, 150, 150, seed=2, related_frac=0.25)
+    got = ctx.sw_score(b)
+    idx = np.arange(0, 65536, 32)
+    assert np.array_equal(got[idx], oracle.sw_batch(b.subset(idx)))
+    swapped = synth.SWBatch(b.bases, b.off.reshape(-1, 2)[:, ::-1].reshape(-1).copy(), b.len.reshape(-1, 2)[:, ::-1].reshape(-1).copy())
+    assert np.array_equal(ctx.sw_score(swapped), got)
+    same = synth.SWBatch(b.bases, np.repeat(b.off[0::2], 2), np.repeat(b.len[0::2], 2))
+    assert np.array_equal(ctx.sw_score(same), b.len[0::2].astype(np.int32))
