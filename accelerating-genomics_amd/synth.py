@@ -258,7 +258,7 @@ def phmm_regions(n_regions: int, reads_per: int, haps_per: int, R: int, H: int, 
             if k:
                 for _s in range(int(rng.integers(1, 4))):
                     h[rng.integers(h.size)] = _ACGT[rng.integers(4)]
-                if rng.random() < 0.5:
+                if H > 3 and rng.random() < 0.5:
                     pos = int(rng.integers(1, H - 1))
                     h = np.delete(h, pos) if rng.random() < 0.5 else np.insert(h, pos, _ACGT[rng.integers(4)])
             hl = H - (int(rng.integers(0, jitter + 1)) if jitter else 0)

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its config, one JSON line on rank 0.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Headline (`value`): Smith-Waterman GCUPS on BASELINE config 2 -- per GPU one batch of 65 536
+pairs, 150x150, iid ACGT + 25 % related pairs, int32 affine-gap scores -- with the packed batch
+already resident in HBM when the clock starts.  A step is one pass of the fill over that batch
+(agx_sw_batch_launch).  GCUPS counts len_a*len_b with the newline sentinel excluded:
+22 500 cells per pair although the kernel fills 151x151.
+
+Second leg, same JSON line under "pairhmm": BASELINE config 3 -- 65 536 (read, haplotype) pairs,
+R=100, H=300, fp32 forward with double rescue -- in pairs/s.
+
+N > 1: every rank owns its own batch of the same shape (independent pairs shard with no
+collective), so scaling is "weak"; torch.distributed (RCCL) is used only for the
+barriers and the max-over-ranks of the timed region.
+
+"roofline": HBM bound as BASELINE.json asks; achieved = algorithmic bytes of one launch
+(304 B/pair SW, 808 B/pair PairHMM) / mean launch duration from HIP events on
+the launch stream.  These kernels are VALU-bound by construction, so the fraction is tiny; the
+"valu" sub-object prices the same launch against the integer/fp32 vector issue rate.
+"cpu_baseline": the reference C program itself (oracle/_ref, compiled in the authoring
+container from the unmodified sources) when present, else the oracle's C port, one core.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SW_PAIRS, SW_LEN = 65536, 150
+PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H = 64, 64, 16, 100, 300
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# vector issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
+
+
+def cpu_baseline_sw(n_pairs):
+    """Time the reference SW program (or the oracle port) on the first n_pairs of the rank-0 workload."""
+    import accelerating_genomics_amd.synth as synth
+
+    b = synth.sw_pairs(n_pairs, SW_LEN, SW_LEN, seed=2, related_frac=0.25)
+    cells = n_pairs * SW_LEN * SW_LEN
+    ref = os.path.join(ROOT, "oracle", "_ref", "sw_ref")
+    if os.access(ref, os.X_OK):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "sw.in")
+            synth.write_sw_file(path, b)
+            t0 = time.perf_counter()
+            out = subprocess.run([ref, path], capture_output=True, check=True)
+            dt = time.perf_counter() - t0
+        assert out.stdout.count(b"Score:") == n_pairs
+        kind = "reference"
+    else:
+        from tests import oracle_api
+
+        orc = oracle_api.load()
+        t0 = time.perf_counter()
+        orc.sw_batch(b, 0)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
+            "sample": "%d of the 65536 config-2 pairs, antidiagonalSmithWaterman.c incl. its text parsing, %.1f s" % (n_pairs, dt)}
+
+
+def cpu_baseline_phmm(n_regions):
+    import accelerating_genomics_amd.synth as synth
+
+    p = synth.phmm_regions(n_regions, PH_READS, PH_HAPS, PH_R, PH_H, seed=3)
+    ref = os.path.join(ROOT, "oracle", "_ref", "phmm_matrix_ref")
+    if os.access(ref, os.X_OK):
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "p.in")
+            synth.write_phmm_file(path, p)
+            t0 = time.perf_counter()
+            subprocess.run([ref, path, os.path.join(d, "p.out")], capture_output=True, check=True)
+            dt = time.perf_counter() - t0
+        kind, what = "reference", "pairHMMmatrix.c (fp64; antidiagsPairHMM.c leaks 24 B/cell, SURVEY.md Q9)"
+    else:
+        from tests import oracle_api
+
+        orc = oracle_api.load()
+        t0 = time.perf_counter()
+        orc.phmm_batch(p, 1)
+        dt = time.perf_counter() - t0
+        kind, what = "port", "oracle antidiag port (fp64)"
+    return {"value": p.n_pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
+            "sample": "%d of the 65536 config-3 pairs, %s, %.1f s" % (p.n_pairs, what, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=32768)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import accelerating_genomics_amd.api as agx
+    import accelerating_genomics_amd.synth as synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    multi = world > 1
+    if agx.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; libagx has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if multi else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE %d; reporting n_gpus=%d" % (args.gpus, world, n_gpus), file=sys.stderr)
+
+    ctx = agx.Context(local_rank)
+
+    def barrier():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    def timed(dev):
+        for _ in range(args.warmup):
+            dev.launch()
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.steps):
+            dev.launch()
+        ev_ms = ctx.timer_stop()  # HIP events on the launch stream (also drains it)
+        barrier()
+        dt = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, ev_ms / args.steps
+
+    # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
+    sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
+    sw_dev = ctx.sw_batch(sw)
+    sw_info = sw_dev.info()
+    sw_dt, sw_launch_ms = timed(sw_dev)
+    sw_scores = sw_dev.scores()
+    sw_cells = sw.cells(sentinel=False)  # 65536 * 22500
+    sw_gcups = n_gpus * sw_cells * args.steps / sw_dt / 1e9
+    sw_bytes = sw.algorithmic_bytes()  # 304 B/pair
+    sw_dev.close()
+
+    # ---------------- PairHMM, BASELINE config 3
+    ph = synth.phmm_regions(PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H, seed=3 + 1000 * rank)
+    ph_dev = ctx.phmm_batch(ph, agx.PHMM_F32)
+    ph_info = ph_dev.info()
+    ph_dt, ph_launch_ms = timed(ph_dev)
+    ph_l, _ = ph_dev.results()
+    ph_rescued = ph_dev.info().n_rescued
+    ph_rate = n_gpus * ph.n_pairs * args.steps / ph_dt
+    ph_bytes = ph.algorithmic_bytes()  # 808 B/pair
+    ph_dev.close()
+
+    if rank != 0:
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile))
+
+    def roof(alg_bytes, launch_ms, key):
+        ach = alg_bytes / (launch_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": (traffic or {}).get(key), "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes}
+
+    out = {
+        "metric": "Smith-Waterman affine-gap score-only GCUPS (config 2: 65536 pairs 150x150 per GPU)",
+        "value": sw_gcups, "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sw_dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: 65536 SW pairs 150x150 per GPU, iid ACGT + 25% related, newline sentinel aligned as the reference does",
+                   "pairs_per_gpu": SW_PAIRS, "len": SW_LEN, "cells_counted_per_pair": SW_LEN * SW_LEN,
+                   "parallelism": "pairs sharded per GPU, no collective"},
+        "roofline": roof(sw_bytes, sw_launch_ms, "sw_fill"),
+        "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
+               "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
+               "valu": {"ops_per_cell": 10.5, "frac_of_int32_issue": (sw_info.padded_cells * 10.5 / (sw_launch_ms * 1e-3)) / VALU_LANE_OPS},
+               "score_checksum": int(sw_scores.astype(np.int64).sum())},
+        "pairhmm": {
+            "metric": "PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)",
+            "value": ph_rate, "unit": "pairs/s", "ms_per_step": ph_dt / args.steps * 1e3, "dtype": "f32",
+            "gcups": n_gpus * ph.cells() * args.steps / ph_dt / 1e9, "rescued_in_f64": int(ph_rescued),
+            "waves": ph_info.n_waves, "launches_per_step": ph_info.n_launches,
+            "useful_cell_fraction": ph_info.cells / max(1, ph_info.padded_cells),
+            "roofline": roof(ph_bytes, ph_launch_ms, "phmm_fill"),
+            "valu": {"flops_per_cell": 11, "frac_of_fp32_issue": (ph_info.padded_cells * 11 / (ph_launch_ms * 1e-3)) / VALU_LANE_OPS},
+            "log10_checksum": float(ph_l.sum()),
+        },
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
+        out["pairhmm"]["cpu_baseline"] = cpu_baseline_phmm(max(1, args.cpu_sample_pairs // (PH_READS * PH_HAPS)))
+        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    print(json.dumps(out), flush=True)
+    if multi:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

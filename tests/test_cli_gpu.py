@@ -1,0 +1,76 @@
+"""The drop-in command lines against the recorded behaviour of the reference programs:
+stdout / output file byte-for-byte (the `elapsed` line is the only one allowed to differ)."""
+import glob
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "accelerating-genomics_amd", "bin")
+SW_CASES = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, "tests", "golden", "sw_*.in")))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(os.path.join(BIN, "antidiagsPairHMM")):
+        import accelerating_genomics_amd.api as agx
+
+        agx.build()
+
+
+@pytest.mark.parametrize("name", SW_CASES)
+def test_sw_cli_stdout_identical(golden_dir, name):
+    out = subprocess.run([os.path.join(BIN, "antidiagonalSmithWaterman"), os.path.join(golden_dir, name + ".in")],
+                         capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines(keepends=True)
+    assert lines[-1].startswith(b"elapsed ") and float(lines[-1].split()[1]) >= 0
+    assert b"".join(lines[:-1]) == open(os.path.join(golden_dir, name + ".expect"), "rb").read()
+
+
+def test_sw_cli_usage_and_errors(tmp_path):
+    exe = os.path.join(BIN, "antidiagonalSmithWaterman")
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 1 and r.stderr.startswith(b"Usage: ") and r.stderr.endswith(b" <file_path>\n")
+    r = subprocess.run([exe, str(tmp_path / "nope")], capture_output=True)
+    assert r.returncode == 1 and r.stderr == b"Error opening file: No such file or directory\n"
+    (tmp_path / "empty").write_bytes(b"")
+    r = subprocess.run([exe, str(tmp_path / "empty")], capture_output=True)
+    assert r.returncode == 1 and r.stdout == b"file is empty"
+
+
+@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"])
+def test_phmm_cli_output_file_and_stdout_identical(golden_dir, tmp_path, name):
+    outp = tmp_path / "o.out"
+    r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), os.path.join(golden_dir, name + ".in"), str(outp)],
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want = open(os.path.join(golden_dir, name + ".f.out"), "rb").read()
+    assert outp.read_bytes() == want
+    # stdout of antidiagsPairHMM.c: "#batch: k" per loop turn (incl. the one that meets EOF) + every value
+    lines = r.stdout.splitlines(keepends=True)
+    assert b"".join(l for l in lines if not l.startswith(b"#batch")) == want
+    nb = [l for l in lines if l.startswith(b"#batch")]
+    assert nb == [b"#batch: %d\n" % (i + 1) for i in range(len(nb))] and lines[-1] == nb[-1]
+
+
+def test_phmm_cli_precisions_and_truncation(golden_dir, tmp_path):
+    exe = os.path.join(BIN, "antidiagsPairHMM")
+    src = os.path.join(golden_dir, "phmm_synth.in")
+    want = [float(x) for x in open(os.path.join(golden_dir, "phmm_synth.g17.out")).read().split()]
+    for prec, tol in (("f32", 1e-6), ("f64fma", 1e-12)):
+        outp = tmp_path / (prec + ".out")
+        r = subprocess.run([exe, src, str(outp)], capture_output=True, env=dict(os.environ, AGX_PHMM_PRECISION=prec))
+        assert r.returncode == 0
+        got = [float(x) for x in outp.read_text().split()]
+        assert len(got) == len(want) and all(abs((g - w) / w) <= tol + 6e-7 / abs(w) for g, w in zip(got, want))  # %f keeps 6 decimals
+    data = open(src, "rb").read().split(b"\n")
+    (tmp_path / "cut.in").write_bytes(b"\n".join(data[:14]) + b"\n")
+    r = subprocess.run([exe, str(tmp_path / "cut.in"), str(tmp_path / "cut.out")], capture_output=True)
+    assert r.returncode == 1 and r.stderr == b"Error reading haplotypes.\n"
+    assert (tmp_path / "cut.out").read_bytes() == b"".join(open(os.path.join(golden_dir, "phmm_synth.f.out"), "rb").readlines()[:24])
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 1 and b"<input_file_r> <output_file>" in r.stderr
