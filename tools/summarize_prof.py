@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one markdown summary.
+usage: summarize_prof.py gpurun_out/prof_<tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+d = sys.argv[1]
+print("# rocprofv3 summary (%s)\n" % os.path.basename(d))
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    return name.split("(")[0][:60]
+
+
+for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    print("## kernel stats (`rocprofv3 --kernel-trace --stats`, bench.py --steps 20 --warmup 3)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        print("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+              float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    print()
+for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_trace.csv"), recursive=True):
+    res = {}
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"),
+                  r.get("Workgroup_Size"), r.get("Grid_Size"))
+    print("## per-dispatch resources (kernel trace)\n")
+    print("| kernel | VGPR | AGPR | SGPR | LDS B | scratch | wg | grid |\n|---|---|---|---|---|---|---|---|")
+    for k, v in res.items():
+        print("| %s | %s |" % (k, " | ".join(str(x) for x in v)))
+    print()
+try:
+    print("bench line under the kernel-trace run: `%s`\n" % open(os.path.join(d, "kt_bench.json")).read().strip()[:400])
+except OSError:
+    pass
+
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if agg:
+    print("## PMC counters (separate `--pmc` passes, mean per dispatch)\n")
+    names = sorted({c for k in agg for c in agg[k]})
+    print("| kernel | " + " | ".join(names) + " |")
+    print("|---|" + "---|" * len(names))
+    traffic = {}
+    for k in agg:
+        row = []
+        for c in names:
+            v = agg[k].get(c)
+            row.append("%.4g" % (sum(v) / len(v)) if v else "")
+        print("| %s | %s |" % (k, " | ".join(row)))
+        fs, ws = agg[k].get("FETCH_SIZE"), agg[k].get("WRITE_SIZE")
+        if fs and ws:
+            # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the
+            # bytes of wide coalesced reads -> doubled (upper bound for narrow reads); WRITE_SIZE exact.
+            traffic[k] = {"fetch_kib_raw": sum(fs) / len(fs), "write_kib": sum(ws) / len(ws),
+                          "hbm_bytes_corrected": (2 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024}
+    print()
+    if traffic:
+        print("## HBM traffic per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)\n")
+        for k, v in traffic.items():
+            print("- %s: fetch raw %.1f KiB, write %.1f KiB -> %.3f MB corrected" % (k, v["fetch_kib_raw"], v["write_kib"], v["hbm_bytes_corrected"] / 1e6))
+        json.dump(traffic, open(os.path.join(d, "traffic_raw.json"), "w"), indent=1)
