@@ -15,7 +15,7 @@
 namespace {
 
 constexpr size_t kTabBudget = 16 * 1024; // LDS bytes a wave may spend on several read tables
-constexpr uint32_t kHapSlack = 32;       // zero bytes after every haplotype: any tiling reads in bounds
+constexpr uint32_t kHapSlack = 44;       // zero bytes after every haplotype: any tiling reads in bounds
 
 struct Plan {
     uint32_t out;
@@ -32,7 +32,28 @@ struct ClassLaunch {
     size_t lds_rescue = 0; // same tables with double rows (F32 rescue pass)
 };
 
-void choose_tiling(uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
+// Tuning knob for experiments (not part of the ABI): AGX_PHMM_MAX_C caps the columns per lane.
+int max_cols_per_lane()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_PHMM_MAX_C");
+        const int n = e ? atoi(e) : 0;
+        return n >= 4 ? n : AGX_PHMM_MAX_COLS_PER_LANE;
+    }();
+    return v;
+}
+
+// AGX_PHMM_FORCE_C pins the class (calibration runs only).
+int force_cols_per_lane()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_PHMM_FORCE_C");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
+void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
 {
     int best = -1, bestG = 0;
     double best_cost = 0;
@@ -40,14 +61,18 @@ void choose_tiling(uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
         const int C = kPhClasses[ci];
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
-        const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G));
+        if (C > max_cols_per_lane() && best >= 0) continue;
+        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        const double wgt = kPhClassCost[precision][ci];
+        if (wgt == 0) continue; // class not built for this arithmetic
+        const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G)) * wgt;
         if (best < 0 || cost < best_cost) {
             best = ci;
             bestG = G;
             best_cost = cost;
         }
     }
-    *cls = (uint8_t)best;
+    *cls = (uint8_t)(best < 0 ? 255 : best);
     *G_out = (uint8_t)bestG;
 }
 
@@ -127,7 +152,11 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 p.hap = h;
                 p.R = (uint32_t)R;
                 p.H = (uint32_t)H;
-                choose_tiling(p.R, p.H, &p.cls, &p.G);
+                choose_tiling(precision, p.R, p.H, &p.cls, &p.G);
+                if (p.cls >= kPhNumClasses) {
+                    agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", r, h, p.H);
+                    return AGX_E_LIMIT;
+                }
                 plan.push_back(p);
             }
         }

@@ -35,8 +35,16 @@ struct PhWave {
     uint32_t steps;
 };
 
-static const int kPhClasses[] = {4, 8, 12, 16, 24, 32};
+static const int kPhClasses[] = {4, 8, 12, 16, 20, 24, 28, 32, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
+// Measured lane time per padded cell of each class relative to the best one of its arithmetic
+// (MI355X, tools/calibrate_classes.py, profiles/r01_calibration.log); 0 = class not built
+// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.
+static const double kPhClassCost[3][9] = {
+    {1.540, 1.225, 1.126, 1.046, 1.053, 1.027, 1.000, 1.195, 0},
+    {1.646, 1.234, 1.141, 1.073, 1.073, 1.023, 1.000, 1.181, 0},
+    {1.840, 1.319, 1.181, 1.096, 1.056, 1.056, 1.015, 1.000, 1.019},
+};
 
 // bytes of LDS one table row takes (four probabilities + the read base)
 __host__ __device__ static inline size_t ph_row_bytes(bool f64) { return (f64 ? 8u : 4u) * 4u + 1u; }

@@ -28,11 +28,25 @@
 // once per wave plus one double per pair.  See DESIGN.md.
 #include "agx_phmm.h"
 
+#include <type_traits>
+
+#ifndef AGX_DPP_MOV
+#define AGX_DPP_MOV 0
+#endif
+
 #pragma clang fp contract(off)
 
 namespace {
 
-__device__ __forceinline__ int shr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+// DPP wave_shr:1: lane i receives lane i-1's v; lane 0 (always a group's first lane) overrides it.
+__device__ __forceinline__ int shr1i(int v)
+{
+#if AGX_DPP_MOV
+    return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, false);
+#else
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
+#endif
+}
 __device__ __forceinline__ float shr1(float v) { return __int_as_float(shr1i(__float_as_int(v))); }
 __device__ __forceinline__ double shr1(double v)
 {
@@ -130,9 +144,12 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
     uint32_t hw[HW];
 #pragma unroll
     for (int k = 0; k < HW; ++k) hw[k] = active ? img[g.hap_dw + gl * HW + k] : 0u;
-    bool hn[C];
+    // haplotype 'N' matches every read base (p(), :111-113).  It is rare, so the cell loop exists
+    // twice: without the test when no lane of the wave holds an 'N', with a per-column bit otherwise.
+    unsigned long long nmask = 0;
 #pragma unroll
-    for (int j = 0; j < C; ++j) hn[j] = ((hw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N';
+    for (int j = 0; j < C; ++j)
+        nmask |= (((hw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N' ? 1ull : 0ull) << j;
 
     const T init = sizeof(T) == 8 ? (T)g.init64 : (T)g.init32;
     T M[C], X[C], Y[C];
@@ -147,52 +164,66 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
     const int steps = (int)w.steps;
     const int col0 = gl * C;
 
-    for (int t = 0; t < steps; ++t) {
-        const T q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
-        const uint32_t rc = tc[t];
-        const T pm = 1 - q_r;                          // p(): match or N (:111-113)
-        const T pq = rc == (uint32_t)'N' ? pm : q_r;   //      mismatch
-        const T mm = 1 - (q_i + q_d);                  // mm() (:115-117)
-        const T gm = 1 - q_g;
+    auto fill = [&](auto hapn_tag) {
+        constexpr bool HAPN = decltype(hapn_tag)::value;
+        for (int t = 0; t < steps; ++t) {
+            const T q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
+            const uint32_t rc = tc[t];
+            const T pm = 1 - q_r;                        // p(): match or N (:111-113)
+            const T pq = rc == (uint32_t)'N' ? pm : q_r; //      mismatch
+            const T mm = 1 - (q_i + q_d);                // mm() (:115-117)
+            const T gm = 1 - q_g;
 
-        T lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
-        T acc = shr1(acc_prev);
-        if (start) { // column 0 of rows >= 1 (:168-178)
-            lM = 0;
-            lX = 0;
-            lY = 0;
-            acc = 0;
-        }
-        T dM = pM, dX = pX, dY = pY;
-        pM = lM;
-        pX = lX;
-        pY = lY;
-        T cM = lM, cY = lY;
+            T lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
+            T acc = shr1(acc_prev);
+            if (start) { // column 0 of rows >= 1 (:168-178)
+                lM = 0;
+                lX = 0;
+                lY = 0;
+                acc = 0;
+            }
+            const T dM0 = pM, dX0 = pX, dY0 = pY;
+            pM = lM;
+            pX = lX;
+            pY = lY;
+            // pass A, right to left: M and X in place -- M[i][j] needs row i-1 of column j-1, which
+            // this order has not overwritten yet, so no value has to be copied aside.
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
-            const uint32_t hc = (hw[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            const T oM = M[j], oX = X[j], oY = Y[j];
-            const T prior = (hc == rc || hn[j]) ? pm : pq;
-            const T m = prior * mad<FMA>(mm, dM, gm * (dX + dY)); // :184
-            const T x = mad<FMA>(oM, q_i, oX * q_g);               // :189
-            const T y = mad<FMA>(cM, q_d, cY * q_g);               // :194
-            M[j] = m;
-            X[j] = x;
-            Y[j] = y;
-            dM = oM;
-            dX = oX;
-            dY = oY;
-            cM = m;
-            cY = y;
-        }
-        if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+            for (int j = C - 1; j >= 0; --j) {
+                const uint32_t hc = (hw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                bool match = hc == rc;
+                if constexpr (HAPN) match = match || ((nmask >> j) & 1ull);
+                const T prior = match ? pm : pq;
+                const T dM = j ? M[j > 0 ? j - 1 : 0] : dM0;
+                const T dX = j ? X[j > 0 ? j - 1 : 0] : dX0;
+                const T dY = j ? Y[j > 0 ? j - 1 : 0] : dY0;
+                const T x = mad<FMA>(M[j], q_i, X[j] * q_g);           // :189
+                const T m = prior * mad<FMA>(mm, dM, gm * (dX + dY)); // :184
+                X[j] = x;
+                M[j] = m;
+            }
+            // pass B, left to right: Y[i][j] needs the new M and Y of column j-1 (:194)
+            T cM = lM, cY = lY;
 #pragma unroll
-            for (int j = 0; j < C; ++j)
-                if (col0 + j < H) acc += (M[j] + X[j]);
-            if (gl == G - 1) result = acc;
+            for (int j = 0; j < C; ++j) {
+                const T y = mad<FMA>(cM, q_d, cY * q_g);
+                cM = M[j];
+                cY = y;
+                Y[j] = y;
+            }
+            if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+#pragma unroll
+                for (int j = 0; j < C; ++j)
+                    if (col0 + j < H) acc += (M[j] + X[j]);
+                if (gl == G - 1) result = acc;
+            }
+            acc_prev = acc;
         }
-        acc_prev = acc;
-    }
+    };
+    if (__any(nmask != 0))
+        fill(std::true_type{});
+    else
+        fill(std::false_type{});
 
     if (wanted && gl == G - 1) {
         // the rescue pass stores its (double-scaled) sum negated so the host can tell the scalings apart
@@ -220,6 +251,12 @@ int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTa
                 uint32_t n_waves, const void *lut, double *sums, double rescue_below, unsigned long long *n_rescued,
                 size_t lds, hipStream_t s)
 {
+    if constexpr (C > 32) { // wider than 32 columns only exists in float (VGPR budget)
+        if (mode == 2) return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+        // the double rescue pass of a float batch reuses the float batch's records (rare, may spill)
+        if (mode == 3) return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+        return -2;
+    } else
     switch (mode) {
     case 0: return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
     case 1: return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
@@ -244,8 +281,11 @@ int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, cons
         AGX_PH_CASE(8);
         AGX_PH_CASE(12);
         AGX_PH_CASE(16);
+        AGX_PH_CASE(20);
         AGX_PH_CASE(24);
+        AGX_PH_CASE(28);
         AGX_PH_CASE(32);
+        AGX_PH_CASE(40);
     default: return -2;
     }
 #undef AGX_PH_CASE

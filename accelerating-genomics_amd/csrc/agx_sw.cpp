@@ -15,14 +15,33 @@ struct Tiling {
     int G;
 };
 
-inline int round4(int v) { return (v + 3) & ~3; }
-
-// Lane-steps x columns a pair costs under tiling (C, G), counting the lanes of a wave that
-// cannot host another group: steps * C * 64 / floor(64 / G).
-inline double tiling_cost(int lx, int ly, int C, int G)
+// Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
+// cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
+// by the measured per-cell cost of the class.
+inline double tiling_cost(int ly, int ci, int G)
 {
-    (void)lx;
-    return (double)round4(ly + G - 1) * C * (64.0 / (double)(64 / G));
+    return (double)(ly + G - 1) * kSwClasses[ci] * (64.0 / (double)(64 / G)) * kSwClassCost[ci];
+}
+
+// Tuning knob for experiments (not part of the ABI): AGX_SW_MAX_C caps the columns per lane.
+int max_cols_per_lane()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_SW_MAX_C");
+        const int n = e ? atoi(e) : 0;
+        return n >= 4 ? n : AGX_SW_MAX_COLS_PER_LANE;
+    }();
+    return v;
+}
+
+// AGX_SW_FORCE_C pins the class (calibration runs only; pairs that do not fit 64 lanes fail).
+int force_cols_per_lane()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_SW_FORCE_C");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
 }
 
 Tiling choose_tiling(int lx, int ly)
@@ -33,7 +52,9 @@ Tiling choose_tiling(int lx, int ly)
         const int C = kSwClasses[ci];
         const int G = (lx + C - 1) / C;
         if (G > 64) continue;
-        const double c = tiling_cost(lx, ly, C, G);
+        if (C > max_cols_per_lane() && best.cls >= 0) continue;
+        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        const double c = tiling_cost(ly, ci, G);
         if (best.cls < 0 || c < best_cost || (c == best_cost && C > kSwClasses[best.cls])) {
             best = Tiling{ci, G};
             best_cost = c;
@@ -122,6 +143,10 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             return AGX_E_SYMBOL;
         }
         const Tiling tl = choose_tiling((int)lx, (int)ly);
+        if (tl.cls < 0) {
+            agx_set_error("pair %lld: no lane tiling fits %u columns", (long long)p, lx);
+            return AGX_E_LIMIT;
+        }
         PairPlan pp{};
         pp.pair = (uint32_t)p;
         pp.lx = (uint16_t)lx;
@@ -184,7 +209,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
                 ++i;
             }
             w.n_groups = (uint16_t)n;
-            w.steps = (uint32_t)round4(max_ly + G - 1);
+            w.steps = (uint32_t)(max_ly + G - 1);
             padded += (int64_t)w.steps * 64 * cl.C;
             waves.push_back(w);
         }

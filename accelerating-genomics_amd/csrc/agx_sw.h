@@ -13,8 +13,8 @@ struct SwGroup {
     uint32_t out;   // index into scores[]
 };
 
-// One wavefront: n_groups groups of G lanes, all stepping `steps` rows (multiple of 4,
-// >= max(ly) + G - 1 over its groups).
+// One wavefront: n_groups groups of G lanes, all stepping `steps` rows
+// (= max(ly) + G - 1 over its groups).
 struct SwWave {
     uint32_t first_group;
     uint16_t n_groups;
@@ -26,6 +26,10 @@ struct SwWave {
 // Column-per-lane classes the kernel is instantiated for.
 static const int kSwClasses[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40};
 static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
+// Measured lane time per padded cell of each class, relative to the widest one (MI355X,
+// tools/calibrate_classes.py, profiles/r01_calibration.log): narrow classes amortise the
+// per-step work (DPP shifts, row symbol, loop control) over fewer cells.
+static const double kSwClassCost[] = {1.365, 1.186, 1.117, 1.069, 1.026, 1.015, 1.011, 1.007, 1.004, 1.0};
 
 int agx_sw_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup *groups, const SwWave *waves,
                         uint32_t n_waves, int32_t *scores, hipStream_t s);

@@ -28,6 +28,13 @@
 // 150x150); the kernel is bound by VALU issue (about 11 integer ops per cell), see DESIGN.md.
 #include "agx_sw.h"
 
+#ifndef AGX_SW_UNROLL4
+#define AGX_SW_UNROLL4 1
+#endif
+#ifndef AGX_DPP_MOV
+#define AGX_DPP_MOV 0
+#endif
+
 namespace {
 
 constexpr int kNegInf = -(1 << 20);
@@ -35,8 +42,14 @@ constexpr uint32_t kRowPad = 0x100u; // never equals a byte
 
 __device__ __forceinline__ int shr1(int old, int v)
 {
-    // DPP wave_shr:1 -- lane i receives lane i-1's v; lane 0 keeps `old`.
+    // DPP wave_shr:1 -- lane i receives lane i-1's v.  Lane 0 has no source; it is always the
+    // first lane of a group and substitutes the matrix boundary, so its value is never used.
+#if AGX_DPP_MOV
+    (void)old;
+    return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, false);
+#else
     return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);
+#endif
 }
 
 template <int C>
@@ -70,56 +83,76 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
     const uint32_t *yp = img + g.y_dw;
     auto row_quad = [&](int q) -> uint32_t { return (feeder && q < nyq) ? yp[q] : 0u; };
 
-    int h[C], e[C];
+    // State per owned column: z = H - 4 (what both gap recurrences consume, so it is stored
+    // instead of H) and e = reference P.  Two VGPRs per column.
+    int z[C], e[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        h[j] = 0;
+        z[j] = -4;
         e[j] = kNegInf;
     }
-    int h_last = 0, f_last = kNegInf, diag_in = 0, best = 0;
+    int z_last = -4, f_last = kNegInf, diag_in = -4, best = -4;
     int yc_prev = (int)kRowPad;
 
     uint32_t q0 = row_quad(0), q1 = row_quad(1), q2 = row_quad(2);
-    const int steps = (int)w.steps; // multiple of 4
+    const int steps = (int)w.steps;
+    uint32_t rows = 0;
     int t = 0;
-    for (int q = 0; t < steps; ++q) {
-        uint32_t rows = q0;
+
+    // one row of the lane's C columns
+    auto step = [&]() __attribute__((always_inline)) {
+        const int fresh = (t < ly) ? (int)(rows & 0xffu) : (int)kRowPad;
+        rows >>= 8;
+        int zl = shr1(-4, z_last);
+        int fl = shr1(kNegInf, f_last);
+        int yc = shr1(fresh, yc_prev);
+        if (start) { // column 0: H = 0, Q = -inf (antidiagonalSmithWaterman.c:299-306)
+            zl = -4;
+            fl = kNegInf;
+            yc = fresh;
+        }
+        int zd = diag_in; // H[r-1][first column - 1] - 4
+        diag_in = zl;
+        int zleft = zl, f = fl;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const int xs = (int)((xw[j >> 2] >> (8 * (j & 3))) & 0xffu);
+            const int up = z[j];
+            const int ev = max(up, e[j] - 1);         // reference P, :313
+            f = max(zleft, f - 1);                    // reference Q, :321
+            const int s = zd + (xs == yc ? 5 : 3);    // H_diag +1 / -1, :332
+            const int v = max(max(ev, f), max(s, 0)); // :333
+            const int zn = v - 4;
+            e[j] = ev;
+            z[j] = zn;
+            zd = up;
+            zleft = zn;
+            best = max(best, zn); // :335
+        }
+        z_last = zleft;
+        f_last = f;
+        yc_prev = yc;
+        ++t;
+    };
+
+    const int quads = steps >> 2;
+    for (int q = 0; q < quads; ++q) { // four rows per packed dword of the long sequence
+        rows = q0;
         q0 = q1;
         q1 = q2;
         q2 = row_quad(q + 3);
+#if AGX_SW_UNROLL4
 #pragma unroll
-        for (int b = 0; b < 4; ++b, ++t) {
-            const int fresh = (t < ly) ? (int)((rows >> (8 * b)) & 0xffu) : (int)kRowPad;
-            int hl = shr1(0, h_last);
-            int fl = shr1(kNegInf, f_last);
-            int yc = shr1(fresh, yc_prev);
-            if (start) {
-                hl = 0;
-                fl = kNegInf;
-                yc = fresh;
-            }
-            int hd = diag_in; // H[r-1][first column - 1]
-            diag_in = hl;
-            int hleft = hl, f = fl;
-#pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const int xs = (int)((xw[j >> 2] >> (8 * (j & 3))) & 0xffu);
-                const int up = h[j];
-                const int ev = max(up - 4, e[j] - 1);   // reference P, :313
-                f = max(hleft - 4, f - 1);              // reference Q, :321
-                const int s = hd + (xs == yc ? 1 : -1); // :332
-                const int v = max(max(ev, f), max(s, 0)); // :333
-                e[j] = ev;
-                h[j] = v;
-                hd = up;
-                hleft = v;
-                best = max(best, v); // :335
-            }
-            h_last = hleft;
-            f_last = f;
-            yc_prev = yc;
-        }
+#else
+#pragma unroll 1
+#endif
+        for (int b = 0; b < 4; ++b) step();
     }
+    rows = q0;
+#pragma unroll 1
+    while (t < steps) step(); // 0..3 remaining rows
+
+    best += 4;
 
     // max over the group's lanes (G need not be a power of two)
     for (int o = 1; o < G; o <<= 1) {
