@@ -110,11 +110,10 @@ def main():
     import torch.distributed as dist
 
     import accelerating_genomics_amd.api as agx
+    import accelerating_genomics_amd.dist as agd
     import accelerating_genomics_amd.synth as synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = agd.env_rank()
     multi = world > 1
     if agx.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; libagx has no CPU fallback")
@@ -145,11 +144,7 @@ def main():
         ev_ms = ctx.timer_stop()  # HIP events on the launch stream (also drains it)
         barrier()
         dt = time.perf_counter() - t0
-        if multi:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, ev_ms / args.steps
+        return agd.max_over_ranks(dt, device="cuda"), ev_ms / args.steps
 
     # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
     sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
