@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr size_t kTabBudget = 16 * 1024; // LDS bytes a wave may spend on several read tables
+constexpr size_t kTabBudget = 20 * 1024; // LDS bytes a wave may spend on several read tables (8 waves/CU fit 160 KiB)
 constexpr uint32_t kHapSlack = 44;       // zero bytes after every haplotype: any tiling reads in bounds
 
 struct Plan {
@@ -38,7 +38,7 @@ int max_cols_per_lane()
     static const int v = [] {
         const char *e = getenv("AGX_PHMM_MAX_C");
         const int n = e ? atoi(e) : 0;
-        return n >= 4 ? n : AGX_PHMM_MAX_COLS_PER_LANE;
+        return n >= 4 ? n : kPhClasses[kPhNumClasses - 1];
     }();
     return v;
 }

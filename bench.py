@@ -40,8 +40,9 @@ sys.path.insert(0, ROOT)
 SW_PAIRS, SW_LEN = 65536, 150
 PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H = 64, 64, 16, 100, 300
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# vector issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
+# Measured wave64 issue rates on this chip (tools/valu_microbench.hip, profiles/r01_valu_microbench.log):
+# add/xor/mul class ~65 T lane-op/s; max/max3/cndmask/compare/DPP/fma/f64 class ~38 T lane-op/s.
+VALU_FAST, VALU_SLOW = 65e12, 38e12
 
 
 def cpu_baseline_sw(n_pairs):
@@ -195,7 +196,8 @@ def main():
         "roofline": roof(sw_bytes, sw_launch_ms, "sw_fill"),
         "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
                "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
-               "valu": {"ops_per_cell": 10.5, "frac_of_int32_issue": (sw_info.padded_cells * 10.5 / (sw_launch_ms * 1e-3)) / VALU_LANE_OPS},
+               "valu": {"ops_per_cell": "4 add + 6.5 max/cmp/cndmask",
+                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (4 / VALU_FAST + 6.5 / VALU_SLOW) / (sw_launch_ms * 1e-3)},
                "score_checksum": int(sw_scores.astype(np.int64).sum())},
         "pairhmm": {
             "metric": "PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)",
@@ -204,7 +206,8 @@ def main():
             "waves": ph_info.n_waves, "launches_per_step": ph_info.n_launches,
             "useful_cell_fraction": ph_info.cells / max(1, ph_info.padded_cells),
             "roofline": roof(ph_bytes, ph_launch_ms, "phmm_fill"),
-            "valu": {"flops_per_cell": 11, "frac_of_fp32_issue": (ph_info.padded_cells * 11 / (ph_launch_ms * 1e-3)) / VALU_LANE_OPS},
+            "valu": {"ops_per_cell": "5 mul + 4 add + 3 cmp/cndmask",
+                     "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (9 / VALU_FAST + 3 / VALU_SLOW) / (ph_launch_ms * 1e-3)},
             "log10_checksum": float(ph_l.sum()),
         },
     }
