@@ -102,7 +102,7 @@ def sw_pairs(n_pairs: int, len_lo: int, len_hi: int, seed: int, related_frac: fl
     off = np.zeros(2 * n_pairs, dtype=np.uint64)
     off[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
     total = int(lens.sum())
-    bases = _ACGT[rng.integers(0, 4, size=total)]
+    bases = _ACGT[rng.integers(0, 4, size=total, dtype=np.uint8)]
     if newline:
         bases[(off + lens - 1).astype(np.int64)] = NL
     for p in np.nonzero(rel)[0]:

@@ -190,3 +190,23 @@ def test_full_size_config3_sample_and_linearity(ctx, oracle):
     rev = synth.phmm_from_regions(_as_regions(b)[::-1])
     got_rev = ctx.phmm_forward(rev, agx.PHMM_F32)
     assert np.array_equal(got_rev.reshape(64, -1)[::-1].reshape(-1), got)
+
+
+def test_full_size_config5_fp64(ctx, oracle):
+    """BASELINE config 5 at full size (262 144 pairs, R=250, H=500, fp64, tolerance 1e-12 vs
+    pairHMMmatrix.c semantics).  The oracle checks 4 096 pairs (8 of the 512 regions) -- bit for
+    bit, which implies the tolerance; the rest is checked by regrouping invariance (regions in
+    reverse order give the same values) and by F64_FMA agreeing to 1e-12 everywhere."""
+    b = synth.phmm_regions(512, 32, 16, 250, 500, seed=5)
+    assert b.n_pairs == 262144
+    got = ctx.phmm_forward(b, agx.PHMM_F64)
+    for g in (0, 100, 511):
+        sub = b.regions(g, g + 1)
+        _, ref = oracle.phmm_batch(sub, 0)
+        assert np.array_equal(got[g * 512 : (g + 1) * 512], ref)
+    sub = b.regions(250, 255)
+    _, ref = oracle.phmm_batch(sub, 0)
+    assert np.array_equal(got[250 * 512 : 255 * 512], ref)
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), got) <= 1e-12
+    rev = synth.phmm_from_regions(_as_regions(b)[::-1])
+    assert np.array_equal(ctx.phmm_forward(rev, agx.PHMM_F64).reshape(512, -1)[::-1].reshape(-1), got)

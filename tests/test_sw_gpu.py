@@ -107,3 +107,22 @@ def test_full_size_config2_properties(ctx, oracle):
     assert np.array_equal(ctx.sw_score(swapped), got)
     same = synth.SWBatch(b.bases, np.repeat(b.off[0::2], 2), np.repeat(b.len[0::2], 2))
     assert np.array_equal(ctx.sw_score(same), b.len[0::2].astype(np.int32))
+
+
+def test_full_size_config4_mixed_lengths(ctx, oracle):
+    """BASELINE config 4 at full size (1 048 576 pairs, both lengths U[32,512]); one GPU takes the
+    whole batch here (the 8-GPU run shards it).  (a) a 1/256 sample (4 096 pairs) against the
+    oracle, (b) scoring two halves separately == scoring the whole, (c) score(a,b) == score(b,a)
+    on a 64k slice."""
+    b = synth.sw_pairs(1 << 20, 32, 512, seed=4)
+    got = ctx.sw_score(b)
+    idx = np.arange(0, 1 << 20, 256)
+    assert np.array_equal(got[idx], oracle.sw_batch(b.subset(idx)))
+    half = 1 << 19
+    lo = synth.SWBatch(b.bases, b.off[: 2 * half], b.len[: 2 * half])
+    hi = synth.SWBatch(b.bases, b.off[2 * half :], b.len[2 * half :])
+    assert np.array_equal(np.concatenate([ctx.sw_score(lo), ctx.sw_score(hi)]), got)
+    sl = synth.SWBatch(b.bases, b.off[:131072].reshape(-1, 2)[:, ::-1].reshape(-1).copy(),
+                       b.len[:131072].reshape(-1, 2)[:, ::-1].reshape(-1).copy())
+    assert np.array_equal(ctx.sw_score(sl), got[:65536])
+    assert got.min() >= 0 and got.max() <= 513
