@@ -16,7 +16,7 @@ PHMM_F64, PHMM_F64_FMA, PHMM_F32 = 0, 1, 2
 
 # every symbol include/agx.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "agx_version", "agx_last_error", "agx_device_count", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
+    "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
     "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_timer_start", "agx_ctx_timer_stop",
     "agx_sw_batch_create", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi",

@@ -26,6 +26,23 @@ int agx_device_count(void)
     return n;
 }
 
+int agx_device_name(int device, char *buf, size_t buf_len)
+{
+    if (!buf || buf_len == 0) {
+        agx_set_error("agx_device_name: null buffer");
+        return AGX_E_ARG;
+    }
+    buf[0] = 0;
+    if (device < 0 || device >= agx_device_count()) {
+        agx_set_error("device %d out of range", device);
+        return AGX_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    AGX_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buf_len, "%s", prop.name);
+    return AGX_OK;
+}
+
 int agx_ctx_create(int device, agx_ctx **out)
 {
     if (!out) {

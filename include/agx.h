@@ -57,6 +57,8 @@ typedef struct agx_ctx agx_ctx; /* one device + one HIP stream + reusable worksp
 const char *agx_version(void);
 const char *agx_last_error(void); /* thread-local, never NULL */
 int agx_device_count(void);       /* >= 0; 0 when HIP reports no device */
+/* Marketing name of a device, as hipvers.cpp:388-391 prints it; empty string on failure. */
+int agx_device_name(int device, char *buf, size_t buf_len);
 
 int agx_ctx_create(int device, agx_ctx **out);
 void agx_ctx_destroy(agx_ctx *ctx);

@@ -74,3 +74,25 @@ def test_phmm_cli_precisions_and_truncation(golden_dir, tmp_path):
     assert (tmp_path / "cut.out").read_bytes() == b"".join(open(os.path.join(golden_dir, "phmm_synth.f.out"), "rb").readlines()[:24])
     r = subprocess.run([exe], capture_output=True)
     assert r.returncode == 1 and b"<input_file_r> <output_file>" in r.stderr
+
+
+def test_hipvers_cli(golden_dir, tmp_path):
+    """hipvers <in> <out> <block>: stdout shape of hipvers.cpp:391-483, scores appended to <out>."""
+    exe = os.path.join(BIN, "hipvers")
+    want = b"".join(l for l in open(os.path.join(golden_dir, "sw_150.expect"), "rb").readlines() if l.startswith(b"Score"))
+    outp = tmp_path / "scores.txt"
+    outp.write_bytes(b"previous content\n")
+    for block in ("64", "256"):
+        r = subprocess.run([exe, os.path.join(golden_dir, "sw_150.in"), str(outp), block], capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.splitlines()
+        assert lines[0].startswith(b"[main] Using Device 0: ") and lines[1] == b"num_of_sequences: 256"
+        assert lines[2] == b"[main] block_size: " + block.encode() and lines[3] == b"[main] grid_size: 128"
+        assert lines[4].startswith(b"elapsed ") and len(lines) == 5
+    assert outp.read_bytes() == b"previous content\n" + want + want  # fopen(..., "a")
+    r = subprocess.run([exe, "x"], capture_output=True)
+    assert r.returncode == 1 and b"<input_file_path> <output_file_path> <block_size>" in r.stderr
+    # header promises more alignments than the file holds: the rest is written as Score: 0
+    r = subprocess.run([exe, os.path.join(golden_dir, "sw_hdr_big.in"), str(tmp_path / "big.txt"), "32"], capture_output=True)
+    got = (tmp_path / "big.txt").read_bytes().splitlines()
+    assert r.returncode == 0 and len(got) == 50 and got[6:] == [b"Score: 0"] * 44
