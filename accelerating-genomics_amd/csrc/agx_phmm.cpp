@@ -5,12 +5,15 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 
 #include "agx_internal.h"
+#include "agx_parallel.h"
 
 namespace {
 
@@ -125,9 +128,13 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         return AGX_E_ARG;
     }
 
+    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     // ---- plan
-    std::vector<Plan> plan;
+    std::vector<Plan> gen; // in output order: region, read, haplotype
     int64_t n_pairs = 0, cells = 0;
+    std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
     for (uint32_t g = 0; g < d->n_regions; ++g) {
         const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
         const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
@@ -152,12 +159,19 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 p.hap = h;
                 p.R = (uint32_t)R;
                 p.H = (uint32_t)H;
-                choose_tiling(precision, p.R, p.H, &p.cls, &p.G);
+                const uint32_t key = (uint32_t)R << 16 | (uint32_t)H;
+                auto it = memo.find(key);
+                if (it == memo.end()) {
+                    choose_tiling(precision, p.R, p.H, &p.cls, &p.G);
+                    it = memo.emplace(key, (uint16_t)(p.cls << 8 | p.G)).first;
+                }
+                p.cls = (uint8_t)(it->second >> 8);
+                p.G = (uint8_t)(it->second & 0xff);
                 if (p.cls >= kPhNumClasses) {
                     agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", r, h, p.H);
                     return AGX_E_LIMIT;
                 }
-                plan.push_back(p);
+                gen.push_back(p);
             }
         }
         if (n_pairs > 0x7fffffffLL) {
@@ -165,12 +179,18 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             return AGX_E_LIMIT;
         }
     }
-    std::sort(plan.begin(), plan.end(), [](const Plan &a, const Plan &b) {
-        if (a.cls != b.cls) return a.cls < b.cls;
-        if (a.G != b.G) return a.G > b.G;
-        if (a.read != b.read) return a.read < b.read; // haplotypes of one read stay adjacent: one LDS table
-        return a.hap < b.hap;
-    });
+    // order: class, lanes per group (wide first), then read, haplotype -- haplotypes of one read stay
+    // adjacent (one LDS table).  `gen` is already (read, haplotype)-ordered: one stable counting pass.
+    std::vector<Plan> plan(gen.size());
+    {
+        std::vector<uint32_t> cnt((size_t)kPhNumClasses * 64 + 1, 0);
+        auto bucket = [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); };
+        for (const Plan &p : gen) ++cnt[bucket(p) + 1];
+        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+        for (const Plan &p : gen) plan[cnt[bucket(p)]++] = p;
+    }
+    std::vector<Plan>().swap(gen);
+    const double t_plan = now();
 
     // ---- image: every read and haplotype once
     std::vector<uint32_t> img;
@@ -276,6 +296,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         launches.push_back(cl);
     }
 
+    const double t_pack = now();
     // ---- upload
     agx_phmm_batch *b = new agx_phmm_batch();
     b->ctx = ctx;
@@ -321,6 +342,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         agx_phmm_batch_destroy(b);
         return AGX_E_HIP;
     }
+    if (trace)
+        fprintf(stderr, "[agx_phmm_batch_create] %lld pairs: plan+order %.2f ms, waves+pack %.2f ms, alloc+H2D %.2f ms (%.1f MB)\n",
+                (long long)n_pairs, t_plan - t_begin, t_pack - t_plan, now() - t_pack, img.size() * 4 / 1e6);
     *out = b;
     return AGX_OK;
 }
@@ -404,21 +428,23 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool f32 = b->precision == AGX_PHMM_F32;
-    for (int64_t k = 0; k < b->n_pairs; ++k) {
-        double v = s[k];
-        if (f32) {
-            // the rescue pass stores its double-scaled sum negated so the two scalings stay apart
-            if (std::signbit(v) && v != 0) {
-                v = -v;
-                log10_lik[k] = log10(v) - c64;
+    agx_parallel_for(b->n_pairs, 8192, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t k = lo; k < hi; ++k) {
+            double v = s[k];
+            if (f32) {
+                // the rescue pass stores its double-scaled sum negated so the two scalings stay apart
+                if (std::signbit(v) && v != 0) {
+                    v = -v;
+                    log10_lik[k] = log10(v) - c64;
+                } else {
+                    log10_lik[k] = log10(v) - c32;
+                }
+                s[k] = v;
             } else {
-                log10_lik[k] = log10(v) - c32;
+                log10_lik[k] = log10(v) - c64;
             }
-            s[k] = v;
-        } else {
-            log10_lik[k] = log10(v) - c64;
         }
-    }
+    });
     return AGX_OK;
 }
 

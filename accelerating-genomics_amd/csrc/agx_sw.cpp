@@ -3,10 +3,12 @@
 #include "agx_sw.h"
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <thread>
 
 #include "agx_internal.h"
+#include "agx_parallel.h"
 
 namespace {
 
@@ -119,59 +121,108 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         return AGX_E_LIMIT;
     }
 
-    // ---- plan every pair
-    std::vector<PairPlan> plan;
-    plan.reserve((size_t)n_pairs);
-    int64_t cells = 0;
-    for (int64_t p = 0; p < n_pairs; ++p) {
-        const uint32_t la = len[2 * p], lb = len[2 * p + 1];
-        if ((la || lb) && !bases) {
-            agx_set_error("agx_sw_batch_create: bases is NULL");
-            return AGX_E_ARG;
-        }
-        cells += (int64_t)la * lb;
-        if (la == 0 || lb == 0) continue; // no interior cell: score stays 0
-        const bool second_short = lb < la; // ties keep file order (antidiagonalSmithWaterman.c:229-244)
-        const uint32_t lx = second_short ? lb : la, ly = second_short ? la : lb;
-        if (lx > AGX_SW_MAX_SHORT_LEN || ly > 0xffffu) {
-            agx_set_error("pair %lld: lengths %u x %u exceed the supported %d x 65535", (long long)p, la, lb,
-                          AGX_SW_MAX_SHORT_LEN);
-            return AGX_E_LIMIT;
-        }
-        if (memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb)) {
-            agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)p);
-            return AGX_E_SYMBOL;
-        }
-        const Tiling tl = choose_tiling((int)lx, (int)ly);
-        if (tl.cls < 0) {
-            agx_set_error("pair %lld: no lane tiling fits %u columns", (long long)p, lx);
-            return AGX_E_LIMIT;
-        }
-        PairPlan pp{};
-        pp.pair = (uint32_t)p;
-        pp.lx = (uint16_t)lx;
-        pp.ly = ly;
-        pp.cls = (uint8_t)tl.cls;
-        pp.G = (uint8_t)tl.G;
-        pp.x_is_second = second_short ? 1 : 0;
-        plan.push_back(pp);
+    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    if (n_pairs > 0 && !bases) {
+        for (int64_t p = 0; p < 2 * n_pairs; ++p)
+            if (len[p]) {
+                agx_set_error("agx_sw_batch_create: bases is NULL");
+                return AGX_E_ARG;
+            }
     }
-    // class, then lanes per group, then long rows first: waves end up homogeneous and the
-    // longest waves of a launch are dispatched first.
-    std::sort(plan.begin(), plan.end(), [](const PairPlan &a, const PairPlan &b) {
-        if (a.cls != b.cls) return a.cls < b.cls;
-        if (a.G != b.G) return a.G > b.G;
-        if (a.ly != b.ly) return a.ly > b.ly;
-        return a.pair < b.pair;
-    });
 
-    // ---- form waves and pack the image
+    // ---- plan every pair (threads over pairs): validate, orient, choose the lane tiling
+    std::vector<PairPlan> all((size_t)n_pairs);
+    struct Worker {
+        int rc = AGX_OK;
+        int64_t bad_pair = -1;
+        int64_t cells = 0;
+    };
+    std::vector<Worker> wk((size_t)agx_host_threads());
+    agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
+        Worker &me = wk[(size_t)tid];
+        for (int64_t p = lo; p < hi; ++p) {
+            PairPlan &pp = all[(size_t)p];
+            pp = PairPlan{};
+            pp.pair = (uint32_t)p;
+            pp.cls = 255; // 255 = nothing to fill
+            const uint32_t la = len[2 * p], lb = len[2 * p + 1];
+            me.cells += (int64_t)la * lb;
+            if (la == 0 || lb == 0) continue; // no interior cell: score stays 0
+            const bool second_short = lb < la; // ties keep file order (antidiagonalSmithWaterman.c:229-244)
+            const uint32_t lx = second_short ? lb : la, ly = second_short ? la : lb;
+            int rc = AGX_OK;
+            Tiling tl{-1, 0};
+            if (lx > AGX_SW_MAX_SHORT_LEN || ly > 0xffffu) rc = AGX_E_LIMIT;
+            else if (memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb)) rc = AGX_E_SYMBOL;
+            else {
+                tl = choose_tiling((int)lx, (int)ly);
+                if (tl.cls < 0) rc = AGX_E_LIMIT;
+            }
+            if (rc != AGX_OK) {
+                if (me.rc == AGX_OK) {
+                    me.rc = rc;
+                    me.bad_pair = p;
+                }
+                continue;
+            }
+            pp.lx = (uint16_t)lx;
+            pp.ly = ly;
+            pp.cls = (uint8_t)tl.cls;
+            pp.G = (uint8_t)tl.G;
+            pp.x_is_second = second_short ? 1 : 0;
+        }
+    });
+    int64_t cells = 0;
+    for (const Worker &w : wk) cells += w.cells;
+    for (const Worker &w : wk)
+        if (w.rc != AGX_OK) {
+            const int64_t p = w.bad_pair;
+            if (w.rc == AGX_E_SYMBOL)
+                agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)p);
+            else
+                agx_set_error("pair %lld: lengths %u x %u exceed the supported %d x 65535 (shorter x longer)", (long long)p,
+                              len[2 * p], len[2 * p + 1], AGX_SW_MAX_SHORT_LEN);
+            return w.rc;
+        }
+    const double t_plan = now();
+
+    // ---- order: class, then lanes per group (wide first), then long rows first, then file order;
+    // waves end up homogeneous and the longest waves of a launch are dispatched first.
+    // Two stable counting passes (LSD): by ly descending, then by (class, G descending).
+    std::vector<PairPlan> plan;
+    {
+        uint32_t max_ly = 0;
+        size_t n_fill = 0;
+        for (const PairPlan &pp : all)
+            if (pp.cls != 255) {
+                max_ly = std::max(max_ly, pp.ly);
+                ++n_fill;
+            }
+        std::vector<uint32_t> cnt((size_t)max_ly + 2, 0);
+        for (const PairPlan &pp : all)
+            if (pp.cls != 255) ++cnt[(size_t)(max_ly - pp.ly) + 1];
+        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+        std::vector<PairPlan> tmp(n_fill);
+        for (const PairPlan &pp : all)
+            if (pp.cls != 255) tmp[cnt[(size_t)(max_ly - pp.ly)]++] = pp;
+        std::vector<uint32_t> cnt2((size_t)kSwNumClasses * 64 + 1, 0);
+        auto bucket = [](const PairPlan &pp) { return (size_t)pp.cls * 64 + (size_t)(64 - pp.G); };
+        for (const PairPlan &pp : tmp) ++cnt2[bucket(pp) + 1];
+        for (size_t k = 1; k < cnt2.size(); ++k) cnt2[k] += cnt2[k - 1];
+        plan.resize(n_fill);
+        for (const PairPlan &pp : tmp) plan[cnt2[bucket(pp)]++] = pp;
+    }
+    std::vector<PairPlan>().swap(all);
+    const double t_sort = now();
+
+    // ---- form waves and lay out the image (offsets only), then copy the bytes with threads
     std::vector<SwGroup> groups(plan.size());
     std::vector<SwWave> waves;
-    std::vector<uint32_t> img;
-    img.reserve((size_t)(cells ? 1024 : 16));
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
+    size_t img_dw = 0;
     size_t i = 0;
     while (i < plan.size()) {
         const int cls = plan[i].cls;
@@ -187,20 +238,16 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             int n = 0, max_ly = 0;
             while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
                 const PairPlan &pp = plan[i];
-                const uint64_t ox = off[2 * (uint64_t)pp.pair + pp.x_is_second];
-                const uint64_t oy = off[2 * (uint64_t)pp.pair + (pp.x_is_second ^ 1)];
                 SwGroup g;
                 const size_t xdw = (size_t)G * cl.C / 4, ydw = ((size_t)pp.ly + 3) / 4;
-                if (img.size() + xdw + ydw > 0xffffffffull) {
+                if (img_dw + xdw + ydw > 0xffffffffull) {
                     agx_set_error("packed image exceeds 16 GiB; split the batch");
                     return AGX_E_LIMIT;
                 }
-                g.x_dw = (uint32_t)img.size();
-                img.resize(img.size() + xdw, 0u);
-                memcpy((uint8_t *)&img[g.x_dw], bases + ox, pp.lx);
-                g.y_dw = (uint32_t)img.size();
-                img.resize(img.size() + ydw, 0u);
-                memcpy((uint8_t *)&img[g.y_dw], bases + oy, pp.ly);
+                g.x_dw = (uint32_t)img_dw;
+                img_dw += xdw;
+                g.y_dw = (uint32_t)img_dw;
+                img_dw += ydw;
                 g.lx_ly = (uint32_t)pp.lx | (pp.ly << 16);
                 g.out = pp.pair;
                 groups[i] = g;
@@ -216,7 +263,36 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
         launches.push_back(cl);
     }
+    struct ImgBuf { // uninitialised storage: every byte is written below (data or zero padding)
+        uint32_t *p = nullptr;
+        size_t n = 0;
+        ~ImgBuf() { free(p); }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        const uint32_t *data() const { return p; }
+    } img;
+    img.n = img_dw;
+    img.p = (uint32_t *)malloc(std::max<size_t>(img_dw, 4) * 4);
+    if (!img.p) {
+        agx_set_error("agx_sw_batch_create: out of host memory for the packed image");
+        return AGX_E_NOMEM;
+    }
+    agx_parallel_for((int64_t)plan.size(), 2048, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const PairPlan &pp = plan[(size_t)k];
+            const SwGroup &g = groups[(size_t)k];
+            const uint64_t ox = off[2 * (uint64_t)pp.pair + pp.x_is_second];
+            const uint64_t oy = off[2 * (uint64_t)pp.pair + (pp.x_is_second ^ 1)];
+            uint8_t *x = (uint8_t *)(img.p + g.x_dw), *y = (uint8_t *)(img.p + g.y_dw);
+            const size_t xb = (size_t)(g.y_dw - g.x_dw) * 4, yb = (((size_t)pp.ly + 3) / 4) * 4;
+            memcpy(x, bases + ox, pp.lx);
+            memset(x + pp.lx, 0, xb - pp.lx);
+            memcpy(y, bases + oy, pp.ly);
+            memset(y + pp.ly, 0, yb - pp.ly);
+        }
+    });
 
+    const double t_pack = now();
     // ---- device image
     agx_sw_batch *b = new agx_sw_batch();
     b->ctx = ctx;
@@ -249,6 +325,9 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         agx_sw_batch_destroy(b);
         return AGX_E_HIP;
     }
+    if (trace)
+        fprintf(stderr, "[agx_sw_batch_create] %lld pairs: plan %.2f ms, sort %.2f ms, pack %.2f ms, alloc+H2D %.2f ms (%.1f MB)\n",
+                (long long)n_pairs, t_plan - t_begin, t_sort - t_plan, t_pack - t_sort, now() - t_pack, img.size() * 4 / 1e6);
     *out = b;
     return AGX_OK;
 }
