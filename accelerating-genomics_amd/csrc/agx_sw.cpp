@@ -17,12 +17,24 @@ struct Tiling {
     int G;
 };
 
+// AGX_SW_KERNEL=i32 selects the scalar int32 kernel; default is the packed int16 one (two pairs
+// per lane group, agx_sw_pk_kernel.hip).  Scores are identical.
+bool use_packed_kernel()
+{
+    static const bool v = [] {
+        const char *e = getenv("AGX_SW_KERNEL");
+        return !(e && strcmp(e, "i32") == 0);
+    }();
+    return v;
+}
+
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
 // cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
 // by the measured per-cell cost of the class.
 inline double tiling_cost(int ly, int ci, int G)
 {
-    return (double)(ly + G - 1) * kSwClasses[ci] * (64.0 / (double)(64 / G)) * kSwClassCost[ci];
+    const double wgt = use_packed_kernel() ? kSwPkClassCost[ci] : kSwClassCost[ci];
+    return (double)(ly + G - 1) * kSwClasses[ci] * (64.0 / (double)(64 / G)) * wgt;
 }
 
 // Tuning knob for experiments (not part of the ABI): AGX_SW_MAX_C caps the columns per lane.
@@ -83,6 +95,7 @@ struct ClassLaunch {
 
 struct agx_sw_batch {
     agx_ctx *ctx = nullptr;
+    bool packed = false;
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
     std::vector<ClassLaunch> launches;
@@ -217,12 +230,21 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
     std::vector<PairPlan>().swap(all);
     const double t_sort = now();
 
-    // ---- form waves and lay out the image (offsets only), then copy the bytes with threads
-    std::vector<SwGroup> groups(plan.size());
+    // ---- form waves and lay out the image (offsets only), then copy the bytes with threads.
+    // Packed kernel: a group carries up to two pairs (slots); the int32 kernel one.
+    const bool packed = use_packed_kernel();
+    const int slots = packed ? 2 : 1;
+    struct Slot {
+        int32_t plan[2]; // indices into plan[], -1 = empty second slot
+    };
+    std::vector<Slot> gslots;
+    gslots.reserve(plan.size() / slots + 16);
     std::vector<SwWave> waves;
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
-    size_t img_dw = 0;
+    // word 0.. of the image: a zero block any empty slot points at (x of up to 64*40 bytes)
+    size_t img_dw = packed ? (size_t)AGX_SW_MAX_SHORT_LEN / 4 : 0;
+    std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
     size_t i = 0;
     while (i < plan.size()) {
         const int cls = plan[i].cls;
@@ -233,36 +255,63 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             const int G = plan[i].G;
             const int per_wave = 64 / G;
             SwWave w{};
-            w.first_group = (uint32_t)i;
+            w.first_group = (uint32_t)gslots.size();
             w.G = (uint16_t)G;
             int n = 0, max_ly = 0;
             while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
-                const PairPlan &pp = plan[i];
-                SwGroup g;
-                const size_t xdw = (size_t)G * cl.C / 4, ydw = ((size_t)pp.ly + 3) / 4;
-                if (img_dw + xdw + ydw > 0xffffffffull) {
-                    agx_set_error("packed image exceeds 16 GiB; split the batch");
-                    return AGX_E_LIMIT;
+                Slot sl{{-1, -1}};
+                for (int k = 0; k < slots && i < plan.size() && plan[i].cls == cls && plan[i].G == G; ++k, ++i) {
+                    const PairPlan &pp = plan[i];
+                    const size_t xdw = (size_t)G * cl.C / 4, ydw = ((size_t)pp.ly + 3) / 4;
+                    if (img_dw + xdw + ydw > 0xffffffffull) {
+                        agx_set_error("packed image exceeds 16 GiB; split the batch");
+                        return AGX_E_LIMIT;
+                    }
+                    x_dw[i] = (uint32_t)img_dw;
+                    img_dw += xdw;
+                    y_dw[i] = (uint32_t)img_dw;
+                    img_dw += ydw;
+                    sl.plan[k] = (int32_t)i;
+                    max_ly = std::max(max_ly, (int)pp.ly);
                 }
-                g.x_dw = (uint32_t)img_dw;
-                img_dw += xdw;
-                g.y_dw = (uint32_t)img_dw;
-                img_dw += ydw;
-                g.lx_ly = (uint32_t)pp.lx | (pp.ly << 16);
-                g.out = pp.pair;
-                groups[i] = g;
-                max_ly = std::max(max_ly, (int)pp.ly);
+                gslots.push_back(sl);
                 ++n;
-                ++i;
             }
             w.n_groups = (uint16_t)n;
             w.steps = (uint32_t)(max_ly + G - 1);
-            padded += (int64_t)w.steps * 64 * cl.C;
+            padded += (int64_t)w.steps * 64 * cl.C * slots;
             waves.push_back(w);
         }
         cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
         launches.push_back(cl);
     }
+    // group records
+    std::vector<SwGroup> groups1(packed ? 0 : gslots.size());
+    std::vector<SwGroup2> groups2(packed ? gslots.size() : 0);
+    for (size_t k = 0; k < gslots.size(); ++k) {
+        for (int h = 0; h < slots; ++h) {
+            const int32_t pi = gslots[k].plan[h];
+            uint32_t xd = 0, yd = 0, ll = 0, out = (uint32_t)n_pairs; // empty slot: zero block, spare score
+            if (pi >= 0) {
+                const PairPlan &pp = plan[(size_t)pi];
+                xd = x_dw[(size_t)pi];
+                yd = y_dw[(size_t)pi];
+                ll = (uint32_t)pp.lx | (pp.ly << 16);
+                out = pp.pair;
+            }
+            if (packed) {
+                groups2[k].x_dw[h] = xd;
+                groups2[k].y_dw[h] = yd;
+                groups2[k].lx_ly[h] = ll;
+                groups2[k].out[h] = out;
+            } else {
+                groups1[k] = SwGroup{xd, yd, ll, out};
+            }
+        }
+    }
+    const void *groups_data = packed ? (const void *)groups2.data() : (const void *)groups1.data();
+    const size_t groups_bytes = packed ? groups2.size() * sizeof(SwGroup2) : groups1.size() * sizeof(SwGroup);
+
     struct ImgBuf { // uninitialised storage: every byte is written below (data or zero padding)
         uint32_t *p = nullptr;
         size_t n = 0;
@@ -277,14 +326,14 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         agx_set_error("agx_sw_batch_create: out of host memory for the packed image");
         return AGX_E_NOMEM;
     }
+    if (packed) memset(img.p, 0, (size_t)AGX_SW_MAX_SHORT_LEN);
     agx_parallel_for((int64_t)plan.size(), 2048, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             const PairPlan &pp = plan[(size_t)k];
-            const SwGroup &g = groups[(size_t)k];
             const uint64_t ox = off[2 * (uint64_t)pp.pair + pp.x_is_second];
             const uint64_t oy = off[2 * (uint64_t)pp.pair + (pp.x_is_second ^ 1)];
-            uint8_t *x = (uint8_t *)(img.p + g.x_dw), *y = (uint8_t *)(img.p + g.y_dw);
-            const size_t xb = (size_t)(g.y_dw - g.x_dw) * 4, yb = (((size_t)pp.ly + 3) / 4) * 4;
+            uint8_t *x = (uint8_t *)(img.p + x_dw[(size_t)k]), *y = (uint8_t *)(img.p + y_dw[(size_t)k]);
+            const size_t xb = (size_t)(y_dw[(size_t)k] - x_dw[(size_t)k]) * 4, yb = (((size_t)pp.ly + 3) / 4) * 4;
             memcpy(x, bases + ox, pp.lx);
             memset(x + pp.lx, 0, xb - pp.lx);
             memcpy(y, bases + oy, pp.ly);
@@ -301,21 +350,22 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
     b->info.padded_cells = padded;
-    b->info.input_bytes = (int64_t)(img.size() * 4 + groups.size() * sizeof(SwGroup) + waves.size() * sizeof(SwWave));
+    b->packed = packed;
+    b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
     b->info.n_launches = (int32_t)launches.size();
     b->info.n_waves = (int32_t)waves.size();
     rc = b->img.alloc(img.size() * 4);
-    if (!rc) rc = b->groups.alloc(groups.size() * sizeof(SwGroup));
+    if (!rc) rc = b->groups.alloc(groups_bytes);
     if (!rc) rc = b->waves.alloc(waves.size() * sizeof(SwWave));
-    if (!rc) rc = b->scores.alloc((size_t)n_pairs * sizeof(int32_t));
+    if (!rc) rc = b->scores.alloc(((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of empty packed halves
     if (rc) {
         agx_sw_batch_destroy(b);
         return rc;
     }
     hipError_t e = hipSuccess;
     if (!img.empty()) e = hipMemcpy(b->img.p, img.data(), img.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !groups.empty())
-        e = hipMemcpy(b->groups.p, groups.data(), groups.size() * sizeof(SwGroup), hipMemcpyHostToDevice);
+    if (e == hipSuccess && groups_bytes)
+        e = hipMemcpy(b->groups.p, groups_data, groups_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && !waves.empty())
         e = hipMemcpy(b->waves.p, waves.data(), waves.size() * sizeof(SwWave), hipMemcpyHostToDevice);
     // pairs with an empty side are never touched by a kernel: their score is this zero
@@ -341,9 +391,13 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
     for (const ClassLaunch &cl : b->launches) {
-        const int r = agx_sw_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
-                                          (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                          (int32_t *)b->scores.p, b->ctx->stream);
+        const int r = b->packed
+                          ? agx_sw_pk_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
+                                                   (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
+                                                   (int32_t *)b->scores.p, b->ctx->stream)
+                          : agx_sw_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
+                                                (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
+                                                (int32_t *)b->scores.p, b->ctx->stream);
         if (r) {
             agx_set_error("sw_fill<%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;

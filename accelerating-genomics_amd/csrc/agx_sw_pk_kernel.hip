@@ -1,0 +1,187 @@
+// Smith-Waterman fill, packed variant: the same wavefront schedule as agx_sw_kernel.hip, but
+// every group of G lanes carries TWO alignment pairs at once -- pair A in the low 16 bits and
+// pair B in the high 16 bits of each state register -- and the cell recurrence runs on packed
+// 16-bit VALU instructions (v_pk_add_i16 / v_pk_max_i16 / v_pk_min_u16 / v_pk_sub_i16).
+//
+// Why: on gfx950 v_max_i32 / v_max3_i32 / v_cndmask issue at about half the rate of v_add_u32,
+// and one packed instruction costs the same issue slot as one of those slow ones while doing two
+// cells (tools/valu_microbench.hip, profiles/r01_valu_microbench.log).  13 packed instructions per
+// 2 cells replace 2 x 10.5 scalar ones.
+//
+// Exactness: scores are bounded by the shorter length (<= 2560 < 32767) and the gap states by
+// -4 and the -inf stand-in, so int16 lanes hold every value of the reference recurrence
+// (antidiagonalSmithWaterman.c:313,:321,:332-335) without wrap-around; results are bit-identical
+// to the int32 kernel.  Symbols are compared as (byte << 1): x ^ y is then 0 on a match and >= 2
+// otherwise, so min(x ^ y, 2) is 0 / 2 = the score difference between match and mismatch.
+#include "agx_sw.h"
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+constexpr short kNeg16 = -16000;     // -inf stand-in; never decremented more than once before a max
+constexpr uint32_t kRowPad16 = 0x200; // (0x100 << 1): never equals (byte << 1)
+
+__device__ __forceinline__ s16x2 splat(short v) { return s16x2{v, v}; }
+__device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+__device__ __forceinline__ uint32_t shr1u(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); // wave_shr:1
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
+                                                  const SwWave *__restrict__ waves, uint32_t n_waves,
+                                                  int32_t *__restrict__ scores)
+{
+    static_assert(C % 4 == 0, "columns per lane are loaded as packed dwords");
+    constexpr int XW = C / 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x & 63;
+    const SwWave w = waves[wave];
+    const int G = w.G;
+    const int grp = lane / G;
+    const int gl = lane - grp * G;
+    const bool active = grp < (int)w.n_groups;
+    const bool start = gl == 0;
+    const bool feeder = active && start;
+
+    SwGroup2 g;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) g.x_dw[k] = g.y_dw[k] = g.lx_ly[k] = g.out[k] = 0;
+    if (active) g = groups[w.first_group + grp];
+    const int lyA = (int)(g.lx_ly[0] >> 16), lyB = (int)(g.lx_ly[1] >> 16);
+    const int nqA = (lyA + 3) >> 2, nqB = (lyB + 3) >> 2;
+
+    // this lane's C symbols of both short sequences -> one register per column: (a << 1) | (b << 1) << 16
+    uint32_t xq[C];
+#pragma unroll
+    for (int k = 0; k < XW; ++k) {
+        const uint32_t a = active ? img[g.x_dw[0] + gl * XW + k] : 0u;
+        const uint32_t b = active ? img[g.x_dw[1] + gl * XW + k] : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xq[4 * k + i] = (((a >> (8 * i)) & 0xffu) << 1) | (((b >> (8 * i)) & 0xffu) << 17);
+    }
+
+    const uint32_t *ypA = img + g.y_dw[0], *ypB = img + g.y_dw[1];
+    auto quadA = [&](int q) -> uint32_t { return (feeder && q < nqA) ? ypA[q] : 0u; };
+    auto quadB = [&](int q) -> uint32_t { return (feeder && q < nqB) ? ypB[q] : 0u; };
+
+    // state per owned column: z = H - 4 and e = reference P, both pairs packed
+    s16x2 z[C], e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        z[j] = splat(-4);
+        e[j] = splat(kNeg16);
+    }
+    s16x2 z_last = splat(-4), f_last = splat(kNeg16), diag_in = splat(-4), best = splat(-4);
+    uint32_t yc_prev = kRowPad16 | (kRowPad16 << 16);
+
+    uint32_t a0 = quadA(0), a1 = quadA(1), a2 = quadA(2);
+    uint32_t b0 = quadB(0), b1 = quadB(1), b2 = quadB(2);
+    const int steps = (int)w.steps;
+    uint32_t rowsA = 0, rowsB = 0;
+    int t = 0;
+
+    auto step = [&]() __attribute__((always_inline)) {
+        const uint32_t fa = (t < lyA) ? ((rowsA & 0xffu) << 1) : kRowPad16;
+        const uint32_t fb = (t < lyB) ? ((rowsB & 0xffu) << 1) : kRowPad16;
+        rowsA >>= 8;
+        rowsB >>= 8;
+        const uint32_t fresh = fa | (fb << 16);
+        s16x2 zl = as_s(shr1u(0, as_u(z_last)));
+        s16x2 fl = as_s(shr1u(0, as_u(f_last)));
+        uint32_t yc = shr1u(fresh, yc_prev);
+        if (start) { // column 0: H = 0, Q = -inf (antidiagonalSmithWaterman.c:299-306)
+            zl = splat(-4);
+            fl = splat(kNeg16);
+            yc = fresh;
+        }
+        s16x2 zd = diag_in; // H[r-1][first column - 1] - 4
+        diag_in = zl;
+        s16x2 zleft = zl, f = fl;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const s16x2 up = z[j];
+            const s16x2 ev = pmax(up, e[j] + splat(-1));   // reference P, :313
+            f = pmax(zleft, f + splat(-1));                 // reference Q, :321
+            const u16x2 d = __builtin_bit_cast(u16x2, xq[j] ^ yc);
+            const u16x2 m2 = __builtin_elementwise_min(d, u16x2{2, 2}); // 0 on a match, 2 otherwise
+            const s16x2 s = (zd + splat(5)) - __builtin_bit_cast(s16x2, m2); // H_diag +1 / -1, :332
+            const s16x2 v = pmax(pmax(ev, f), pmax(s, splat(0)));     // :333
+            const s16x2 zn = v + splat(-4);
+            e[j] = ev;
+            z[j] = zn;
+            zd = up;
+            zleft = zn;
+            best = pmax(best, zn); // :335
+        }
+        z_last = zleft;
+        f_last = f;
+        yc_prev = yc;
+        ++t;
+    };
+
+    const int quads = steps >> 2;
+    for (int q = 0; q < quads; ++q) {
+        rowsA = a0;
+        a0 = a1;
+        a1 = a2;
+        a2 = quadA(q + 3);
+        rowsB = b0;
+        b0 = b1;
+        b1 = b2;
+        b2 = quadB(q + 3);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) step();
+    }
+    rowsA = a0;
+    rowsB = b0;
+#pragma unroll 1
+    while (t < steps) step();
+
+    // max over the group's lanes (G need not be a power of two), both halves at once
+    for (int o = 1; o < G; o <<= 1) {
+        const s16x2 other = as_s((uint32_t)__shfl_down((int)as_u(best), o));
+        if (gl + o < G) best = pmax(best, other);
+    }
+    if (feeder) {
+        scores[g.out[0]] = (int)best[0] + 4;
+        scores[g.out[1]] = (int)best[1] + 4; // a group without a second pair points this at the spare slot
+    }
+}
+
+template <int C>
+int launch(const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves, int32_t *scores,
+           hipStream_t s)
+{
+    const uint32_t blocks = (n_waves + 3) / 4;
+    hipLaunchKernelGGL(sw_fill_pk<C>, dim3(blocks), dim3(256), 0, s, img, groups, waves, n_waves, scores);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace
+
+int agx_sw_pk_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves,
+                           uint32_t n_waves, int32_t *scores, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    switch (cols_per_lane) {
+    case 4: return launch<4>(img, groups, waves, n_waves, scores, s);
+    case 8: return launch<8>(img, groups, waves, n_waves, scores, s);
+    case 12: return launch<12>(img, groups, waves, n_waves, scores, s);
+    case 16: return launch<16>(img, groups, waves, n_waves, scores, s);
+    case 20: return launch<20>(img, groups, waves, n_waves, scores, s);
+    case 24: return launch<24>(img, groups, waves, n_waves, scores, s);
+    case 28: return launch<28>(img, groups, waves, n_waves, scores, s);
+    case 32: return launch<32>(img, groups, waves, n_waves, scores, s);
+    case 36: return launch<36>(img, groups, waves, n_waves, scores, s);
+    case 40: return launch<40>(img, groups, waves, n_waves, scores, s);
+    default: return -2;
+    }
+}

@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Headline (`value`): Smith-Waterman GCUPS on BASELINE config 2 -- per GPU one batch of 65 536
-pairs, 150x150, iid ACGT + 25 % related pairs, int32 affine-gap scores -- with the packed batch
+pairs, 150x150, iid ACGT + 25 % related pairs, int32 affine-gap scores (computed in packed int16
+lanes, bit-identical) -- with the packed batch
 already resident in HBM when the clock starts.  A step is one pass of the fill over that batch
 (agx_sw_batch_launch).  GCUPS counts len_a*len_b with the newline sentinel excluded:
 22 500 cells per pair although the kernel fills 151x151.
@@ -42,7 +43,8 @@ PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H = 64, 64, 16, 100, 300
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # Measured wave64 issue rates on this chip (tools/valu_microbench.hip, profiles/r01_valu_microbench.log):
 # add/xor/mul class ~65 T lane-op/s; max/max3/cndmask/compare/DPP/fma/f64 class ~38 T lane-op/s.
-VALU_FAST, VALU_SLOW = 65e12, 38e12
+# packed (v_pk_*) instructions ~37.5 T lane-instr/s = 75 T element-op/s.
+VALU_FAST, VALU_SLOW, VALU_PACKED = 65e12, 38e12, 37.5e12
 
 
 def cpu_baseline_sw(n_pairs):
@@ -189,15 +191,15 @@ def main():
         "metric": "Smith-Waterman affine-gap score-only GCUPS (config 2: 65536 pairs 150x150 per GPU)",
         "value": sw_gcups, "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sw_dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic",
+        "dtype": "int16x2 lanes, int32 scores", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: 65536 SW pairs 150x150 per GPU, iid ACGT + 25% related, newline sentinel aligned as the reference does",
                    "pairs_per_gpu": SW_PAIRS, "len": SW_LEN, "cells_counted_per_pair": SW_LEN * SW_LEN,
                    "parallelism": "pairs sharded per GPU, no collective"},
         "roofline": roof(sw_bytes, sw_launch_ms, "sw_fill"),
         "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
                "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
-               "valu": {"ops_per_cell": "4 add + 6.5 max/cmp/cndmask",
-                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (4 / VALU_FAST + 6.5 / VALU_SLOW) / (sw_launch_ms * 1e-3)},
+               "valu": {"ops_per_cell": "13 packed int16 instructions per 2 cells (v_pk_add/max/min/sub_i16 + xor)",
+                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (6.5 / VALU_PACKED) / (sw_launch_ms * 1e-3)},
                "score_checksum": int(sw_scores.astype(np.int64).sum())},
         "pairhmm": {
             "metric": "PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)",
