@@ -79,6 +79,34 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t 
     *G_out = (uint8_t)bestG;
 }
 
+// Uniform batches (most pairs share one (R, H) shape): the launch lasts ceil(waves / SIMDs)
+// wave-times, so the tiling of that shape is chosen with that quantisation.
+void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count, int n_simd, uint8_t *cls, uint8_t *G_out)
+{
+    int best = -1, bestG = 0;
+    double best_cost = 0;
+    for (int ci = 0; ci < kPhNumClasses; ++ci) {
+        const int C = kPhClasses[ci];
+        const int G = (int)((H + C - 1) / C);
+        if (G > 64) continue;
+        if (C > max_cols_per_lane() && best >= 0) continue;
+        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        const double wgt = kPhClassCost[precision][ci];
+        if (wgt == 0) continue;
+        const int64_t per_wave = 64 / G;
+        const int64_t waves = (count + per_wave - 1) / per_wave;
+        const int64_t rounds = (waves + n_simd - 1) / n_simd;
+        const double cost = (double)rounds * (R + G - 1) * C * wgt;
+        if (best < 0 || cost < best_cost) {
+            best = ci;
+            bestG = G;
+            best_cost = cost;
+        }
+    }
+    *cls = (uint8_t)(best < 0 ? 255 : best);
+    *G_out = (uint8_t)bestG;
+}
+
 // 256-entry quality LUT exactly as partition_read() computes it (antidiagsPairHMM.c:104-107)
 void build_lut(double *d, float *f)
 {
@@ -177,6 +205,34 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         if (n_pairs > 0x7fffffffLL) {
             agx_set_error("more than 2^31 pairs in one batch");
             return AGX_E_LIMIT;
+        }
+    }
+    // dominant (R, H) shape?
+    if (gen.size() >= 1024 && ctx->n_cu > 0) {
+        const size_t stride = gen.size() / 512;
+        uint32_t cand = 0;
+        int votes = 0;
+        for (size_t k = 0; k < 512; ++k) {
+            const Plan &p = gen[k * stride];
+            const uint32_t key = p.R << 16 | p.H;
+            if (votes == 0) {
+                cand = key;
+                votes = 1;
+            } else
+                votes += key == cand ? 1 : -1;
+        }
+        int64_t count = 0;
+        for (const Plan &p : gen)
+            if ((p.R << 16 | p.H) == cand) ++count;
+        if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
+            uint8_t c = 255, G = 0;
+            choose_tiling_uniform(precision, cand >> 16, cand & 0xffffu, count, 4 * ctx->n_cu, &c, &G);
+            if (c < kPhNumClasses)
+                for (Plan &p : gen)
+                    if ((p.R << 16 | p.H) == cand) {
+                        p.cls = c;
+                        p.G = G;
+                    }
         }
     }
     // order: class, lanes per group (wide first), then read, haplotype -- haplotypes of one read stay

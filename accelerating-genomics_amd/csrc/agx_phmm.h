@@ -35,15 +35,17 @@ struct PhWave {
     uint32_t steps;
 };
 
-static const int kPhClasses[] = {4, 8, 12, 16, 20, 24, 28, 32, 40};
+#define AGX_PH_FOR_EACH_CLASS(X) \
+    X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic
-// (MI355X, tools/calibrate_classes.py, profiles/r01_calibration.log); 0 = class not built
+// (MI355X, tools/calibrate_classes.py, profiles/r01_calibration*.log); 0 = class not built
 // for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.
-static const double kPhClassCost[3][9] = {
-    {1.540, 1.225, 1.126, 1.046, 1.053, 1.027, 1.000, 1.195, 0},
-    {1.646, 1.234, 1.141, 1.073, 1.073, 1.023, 1.000, 1.181, 0},
-    {1.840, 1.319, 1.181, 1.096, 1.056, 1.056, 1.015, 1.000, 1.019},
+static const double kPhClassCost[3][19] = {
+    {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.220, 0, 0, 0, 0},
+    {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 1.211, 0, 0, 0, 0},
+    {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
 };
 
 // bytes of LDS one table row takes (four probabilities + the read base)

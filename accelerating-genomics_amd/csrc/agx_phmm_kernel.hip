@@ -70,8 +70,7 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
                                                 uint32_t n_waves, const T *__restrict__ lut, double *__restrict__ sums,
                                                 double rescue_below, unsigned long long *__restrict__ n_rescued)
 {
-    static_assert(C % 4 == 0, "columns per lane are loaded as packed dwords");
-    constexpr int HW = C / 4;
+    constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t wave = blockIdx.x; // one wavefront per workgroup
     if (wave >= n_waves) return;
@@ -141,9 +140,17 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
     const T *tq = reinterpret_cast<const T *>(lds + tabi * tab_bytes) + (G - 1 - gl);
     const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + 4 * rows * sizeof(T)) + (G - 1 - gl);
 
+    // lane gl owns haplotype bytes [gl*C, gl*C + C): fetch the covering dwords and byte-align them
+    // (C need not be a multiple of 4; every haplotype is followed by zero slack)
     uint32_t hw[HW];
+    {
+        const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
+        uint32_t raw[HW + 1];
 #pragma unroll
-    for (int k = 0; k < HW; ++k) hw[k] = active ? img[g.hap_dw + gl * HW + k] : 0u;
+        for (int k = 0; k <= HW; ++k) raw[k] = active ? img[g.hap_dw + d0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < HW; ++k) hw[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh);
+    }
     // haplotype 'N' matches every read base (p(), :111-113).  It is rare, so the cell loop exists
     // twice: without the test when no lane of the wave holds an 'N', with a per-column bit otherwise.
     unsigned long long nmask = 0;
@@ -275,17 +282,9 @@ int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, cons
 {
     if (n_waves == 0) return 0;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds_bytes, s)
+    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds_bytes, s);
     switch (cols_per_lane) {
-        AGX_PH_CASE(4);
-        AGX_PH_CASE(8);
-        AGX_PH_CASE(12);
-        AGX_PH_CASE(16);
-        AGX_PH_CASE(20);
-        AGX_PH_CASE(24);
-        AGX_PH_CASE(28);
-        AGX_PH_CASE(32);
-        AGX_PH_CASE(40);
+        AGX_PH_FOR_EACH_CLASS(AGX_PH_CASE)
     default: return -2;
     }
 #undef AGX_PH_CASE

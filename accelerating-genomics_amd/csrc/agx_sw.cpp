@@ -77,6 +77,33 @@ Tiling choose_tiling(int lx, int ly)
     return best;
 }
 
+// Uniform batches (most pairs share one shape, e.g. fixed-length reads): every wave of that shape
+// costs the same, so the launch lasts ceil(waves / SIMDs) wave-times -- the tiling is chosen for the
+// whole shape with that quantisation instead of pair by pair.
+Tiling choose_tiling_uniform(int lx, int ly, int64_t count, int n_simd)
+{
+    Tiling best{-1, 0};
+    double best_cost = 0;
+    const int slots = use_packed_kernel() ? 2 : 1;
+    for (int ci = 0; ci < kSwNumClasses; ++ci) {
+        const int C = kSwClasses[ci];
+        const int G = (lx + C - 1) / C;
+        if (G > 64) continue;
+        if (C > max_cols_per_lane() && best.cls >= 0) continue;
+        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        const int64_t per_wave = (int64_t)(64 / G) * slots;
+        const int64_t waves = (count + per_wave - 1) / per_wave;
+        const int64_t rounds = (waves + n_simd - 1) / n_simd;
+        const double wgt = use_packed_kernel() ? kSwPkClassCost[ci] : kSwClassCost[ci];
+        const double c = (double)rounds * (ly + G - 1) * C * wgt;
+        if (best.cls < 0 || c < best_cost) {
+            best = Tiling{ci, G};
+            best_cost = c;
+        }
+    }
+    return best;
+}
+
 struct PairPlan {
     uint32_t pair;
     uint16_t lx;
@@ -199,6 +226,35 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
                               len[2 * p], len[2 * p + 1], AGX_SW_MAX_SHORT_LEN);
             return w.rc;
         }
+    // dominant shape?  (sampled first, counted only if the sample says so)
+    if (n_pairs >= 1024 && ctx->n_cu > 0) {
+        const size_t stride = (size_t)n_pairs / 512;
+        uint32_t cand = 0;
+        int votes = 0;
+        for (size_t k = 0; k < 512; ++k) { // Boyer-Moore majority vote over a sample
+            const PairPlan &pp = all[k * stride];
+            const uint32_t key = (uint32_t)pp.lx << 16 | (pp.ly & 0xffffu);
+            if (pp.cls == 255) continue;
+            if (votes == 0) {
+                cand = key;
+                votes = 1;
+            } else
+                votes += key == cand ? 1 : -1;
+        }
+        int64_t count = 0;
+        if (votes > 0)
+            for (const PairPlan &pp : all)
+                if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) ++count;
+        if (count * 2 >= n_pairs) {
+            const Tiling tl = choose_tiling_uniform((int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * ctx->n_cu);
+            if (tl.cls >= 0)
+                for (PairPlan &pp : all)
+                    if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) {
+                        pp.cls = (uint8_t)tl.cls;
+                        pp.G = (uint8_t)tl.G;
+                    }
+        }
+    }
     const double t_plan = now();
 
     // ---- order: class, then lanes per group (wide first), then long rows first, then file order;
@@ -243,7 +299,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
     // word 0.. of the image: a zero block any empty slot points at (x of up to 64*40 bytes)
-    size_t img_dw = packed ? (size_t)AGX_SW_MAX_SHORT_LEN / 4 : 0;
+    size_t img_dw = packed ? (size_t)AGX_SW_MAX_SHORT_LEN / 4 + 1 : 0;
     std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
     size_t i = 0;
     while (i < plan.size()) {
@@ -262,7 +318,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
                 Slot sl{{-1, -1}};
                 for (int k = 0; k < slots && i < plan.size() && plan[i].cls == cls && plan[i].G == G; ++k, ++i) {
                     const PairPlan &pp = plan[i];
-                    const size_t xdw = (size_t)G * cl.C / 4, ydw = ((size_t)pp.ly + 3) / 4;
+                    const size_t xdw = ((size_t)G * cl.C + 3) / 4 + 1, ydw = ((size_t)pp.ly + 3) / 4;
                     if (img_dw + xdw + ydw > 0xffffffffull) {
                         agx_set_error("packed image exceeds 16 GiB; split the batch");
                         return AGX_E_LIMIT;
@@ -326,7 +382,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         agx_set_error("agx_sw_batch_create: out of host memory for the packed image");
         return AGX_E_NOMEM;
     }
-    if (packed) memset(img.p, 0, (size_t)AGX_SW_MAX_SHORT_LEN);
+    if (packed) memset(img.p, 0, (size_t)AGX_SW_MAX_SHORT_LEN + 4);
     agx_parallel_for((int64_t)plan.size(), 2048, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             const PairPlan &pp = plan[(size_t)k];

@@ -5,7 +5,8 @@
 #include <cstdint>
 
 // One alignment pair = one group of G lanes.  Offsets are in 4-byte words into the packed
-// image: x (the shorter sequence, zero-padded to G*C bytes), y (the longer, padded to 4).
+// image: x (the shorter sequence, zero-padded to G*C bytes rounded up to 4, plus one spare word),
+// y (the longer, padded to 4).
 struct SwGroup {
     uint32_t x_dw;
     uint32_t y_dw;
@@ -33,15 +34,18 @@ struct SwWave {
     uint32_t reserved;
 };
 
-// Column-per-lane classes the kernel is instantiated for.
-static const int kSwClasses[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40};
+// Column-per-lane classes the kernels are instantiated for (any width works: a lane's symbols are
+// byte-aligned on load), every even width so that common lengths tile with little padding.
+#define AGX_SW_FOR_EACH_CLASS(X) \
+    X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+static const int kSwClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
 // Measured lane time per padded cell of each class, relative to the widest one (MI355X,
-// tools/calibrate_classes.py, profiles/r01_calibration.log): narrow classes amortise the
+// tools/calibrate_classes.py, profiles/r01_calibration*.log): narrow classes amortise the
 // per-step work (DPP shifts, row symbol, loop control) over fewer cells.
-static const double kSwClassCost[] = {1.365, 1.186, 1.117, 1.069, 1.026, 1.015, 1.011, 1.007, 1.004, 1.0};
-// same for the packed int16 kernel (profiles/r01_calibration_pk.log)
-static const double kSwPkClassCost[] = {1.537, 1.280, 1.171, 1.120, 1.063, 1.046, 1.017, 1.017, 1.006, 1.0};
+static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 1.036, 1.025, 1.029, 1.022, 1.018, 1.011, 1.011, 1.007, 1.004, 1.004, 1.004, 1.004, 1.000};
+// same for the packed int16 kernel
+static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000};
 
 int agx_sw_pk_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves,
                            uint32_t n_waves, int32_t *scores, hipStream_t s);

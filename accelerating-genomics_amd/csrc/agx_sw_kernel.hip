@@ -57,8 +57,7 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
                                                const SwWave *__restrict__ waves, uint32_t n_waves,
                                                int32_t *__restrict__ scores)
 {
-    static_assert(C % 4 == 0, "columns per lane are loaded as packed dwords");
-    constexpr int XW = C / 4;
+    constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & 63;
@@ -76,9 +75,17 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
     const int ly = (int)(g.lx_ly >> 16);
     const int nyq = (ly + 3) >> 2;
 
+    // lane gl owns bytes [gl*C, gl*C + C) of the short sequence: fetch the covering dwords and
+    // byte-align them (C need not be a multiple of 4; the block is padded so the extra dword exists)
     uint32_t xw[XW];
+    {
+        const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
+        uint32_t raw[XW + 1];
 #pragma unroll
-    for (int k = 0; k < XW; ++k) xw[k] = active ? img[g.x_dw + gl * XW + k] : 0u;
+        for (int k = 0; k <= XW; ++k) raw[k] = active ? img[g.x_dw + d0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < XW; ++k) xw[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh);
+    }
 
     const uint32_t *yp = img + g.y_dw;
     auto row_quad = [&](int q) -> uint32_t { return (feeder && q < nyq) ? yp[q] : 0u; };
@@ -178,16 +185,10 @@ int agx_sw_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup *g
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
-    case 4: return launch<4>(img, groups, waves, n_waves, scores, s);
-    case 8: return launch<8>(img, groups, waves, n_waves, scores, s);
-    case 12: return launch<12>(img, groups, waves, n_waves, scores, s);
-    case 16: return launch<16>(img, groups, waves, n_waves, scores, s);
-    case 20: return launch<20>(img, groups, waves, n_waves, scores, s);
-    case 24: return launch<24>(img, groups, waves, n_waves, scores, s);
-    case 28: return launch<28>(img, groups, waves, n_waves, scores, s);
-    case 32: return launch<32>(img, groups, waves, n_waves, scores, s);
-    case 36: return launch<36>(img, groups, waves, n_waves, scores, s);
-    case 40: return launch<40>(img, groups, waves, n_waves, scores, s);
+#define AGX_SW_CASE(CC) \
+    case CC: return launch<CC>(img, groups, waves, n_waves, scores, s);
+        AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
+#undef AGX_SW_CASE
     default: return -2;
     }
 }

@@ -38,8 +38,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
                                                   const SwWave *__restrict__ waves, uint32_t n_waves,
                                                   int32_t *__restrict__ scores)
 {
-    static_assert(C % 4 == 0, "columns per lane are loaded as packed dwords");
-    constexpr int XW = C / 4;
+    constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & 63;
@@ -59,13 +58,24 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
     const int nqA = (lyA + 3) >> 2, nqB = (lyB + 3) >> 2;
 
     // this lane's C symbols of both short sequences -> one register per column: (a << 1) | (b << 1) << 16
+    // (lane gl owns bytes [gl*C, gl*C + C) of each short sequence; C need not be a multiple of 4)
     uint32_t xq[C];
+    {
+        const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
+        uint32_t ra[XW + 1], rb[XW + 1];
 #pragma unroll
-    for (int k = 0; k < XW; ++k) {
-        const uint32_t a = active ? img[g.x_dw[0] + gl * XW + k] : 0u;
-        const uint32_t b = active ? img[g.x_dw[1] + gl * XW + k] : 0u;
+        for (int k = 0; k <= XW; ++k) {
+            ra[k] = active ? img[g.x_dw[0] + d0 + k] : 0u;
+            rb[k] = active ? img[g.x_dw[1] + d0 + k] : 0u;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xq[4 * k + i] = (((a >> (8 * i)) & 0xffu) << 1) | (((b >> (8 * i)) & 0xffu) << 17);
+        for (int k = 0; k < XW; ++k) {
+            const uint32_t a = __builtin_amdgcn_alignbyte(ra[k + 1], ra[k], sh);
+            const uint32_t b = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * k + i < C) xq[4 * k + i] = (((a >> (8 * i)) & 0xffu) << 1) | (((b >> (8 * i)) & 0xffu) << 17);
+        }
     }
 
     const uint32_t *ypA = img + g.y_dw[0], *ypB = img + g.y_dw[1];
@@ -172,16 +182,10 @@ int agx_sw_pk_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
-    case 4: return launch<4>(img, groups, waves, n_waves, scores, s);
-    case 8: return launch<8>(img, groups, waves, n_waves, scores, s);
-    case 12: return launch<12>(img, groups, waves, n_waves, scores, s);
-    case 16: return launch<16>(img, groups, waves, n_waves, scores, s);
-    case 20: return launch<20>(img, groups, waves, n_waves, scores, s);
-    case 24: return launch<24>(img, groups, waves, n_waves, scores, s);
-    case 28: return launch<28>(img, groups, waves, n_waves, scores, s);
-    case 32: return launch<32>(img, groups, waves, n_waves, scores, s);
-    case 36: return launch<36>(img, groups, waves, n_waves, scores, s);
-    case 40: return launch<40>(img, groups, waves, n_waves, scores, s);
+#define AGX_SW_CASE(CC) \
+    case CC: return launch<CC>(img, groups, waves, n_waves, scores, s);
+        AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
+#undef AGX_SW_CASE
     default: return -2;
     }
 }

@@ -1,0 +1,23 @@
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+ctx = agx.Context(0)
+def timeit(dev, reps):
+    dev.launch(); ctx.sync()
+    best = 1e9
+    for _ in range(5):
+        ctx.timer_start()
+        for _ in range(reps): dev.launch()
+        best = min(best, ctx.timer_stop()/reps)
+    return best
+b = synth.sw_pairs(65536,150,150,seed=2, related_frac=0.25)
+dev = ctx.sw_batch(b); info = dev.info(); ms = timeit(dev, 50)
+print("SW C2: %.4f ms %.0f GCUPS eff %.3f waves %d" % (ms, 65536*22500/ms/1e6, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()
+b = synth.sw_pairs(262144,32,512,seed=4)
+dev = ctx.sw_batch(b); info = dev.info(); ms = timeit(dev, 5)
+print("SW mixed 256k: %.3f ms %.0f GCUPS eff %.3f launches %d" % (ms, b.cells(False)/ms/1e6, info.cells/info.padded_cells, info.n_launches), flush=True); dev.close()
+for (nr,reads,haps,R,H,name,reps) in ((64,64,16,100,300,"C3",20),(64,32,16,250,500,"C5/8",8)):
+    p = synth.phmm_regions(nr,reads,haps,R,H,seed=3)
+    for prec,pn in ((agx.PHMM_F32,"f32"),(agx.PHMM_F64,"f64"),(agx.PHMM_F64_FMA,"fma")):
+        dev = ctx.phmm_batch(p, prec); info = dev.info(); ms = timeit(dev, reps)
+        print("PHMM %s %s: %.4f ms %.2f Mpairs/s eff %.3f waves %d" % (name, pn, ms, p.n_pairs/ms/1e3, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()

@@ -34,7 +34,10 @@ else:
         print("ph %%s C=%%2d waves %%6d padded %%.3e ms %%.3f  ps/padded-cell %%.3f  Mpairs/s %%.1f" %% (name, C, i.n_waves, i.padded_cells, ms, ms*1e9/i.padded_cells, p.n_pairs/ms/1e3), flush=True)
         dev.close()
 ''' % ROOT
-for C in (4, 8, 12, 16, 20, 24, 28, 32, 36, 40):
-    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="sw", CAL_C=str(C), AGX_SW_FORCE_C=str(C)))
-for C in (4, 8, 12, 16, 20, 24, 28, 32, 40):
+EVEN = tuple(range(4, 42, 2))
+for kern in ("pk", "i32"):
+    print("# SW kernel", kern, flush=True)
+    for C in EVEN:
+        subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="sw", CAL_C=str(C), AGX_SW_FORCE_C=str(C), AGX_SW_KERNEL=kern))
+for C in EVEN:
     subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="ph", CAL_C=str(C), AGX_PHMM_FORCE_C=str(C)))
