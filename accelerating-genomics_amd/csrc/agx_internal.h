@@ -22,12 +22,31 @@ extern "C" void agx_set_error(const char *fmt, ...) __attribute__((format(printf
         }                                                                                      \
     } while (0)
 
+constexpr int kAuxStreams = 3;
+
 struct agx_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 0;
+    // Side streams for batches that need several kernel launches (one per lane-tiling class):
+    // the launches are independent, so they are spread over the main stream and these, forked
+    // and joined with events -- the tail of one class overlaps the head of the next.
+    hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[kAuxStreams] = {nullptr, nullptr, nullptr};
+};
+
+// Usage: FanOut f(ctx, n_launches); f.begin(); ... launch k on f.stream(k) ...; f.end();
+// Everything is ordered after prior work on ctx->stream and before later work on it.
+struct FanOut {
+    agx_ctx *c;
+    int n;
+    bool used[kAuxStreams] = {false, false, false};
+    FanOut(agx_ctx *ctx, int n_launches) : c(ctx), n(n_launches) {}
+    int begin();
+    hipStream_t stream(int k);
+    int end();
 };
 
 // RAII-less device buffer (freed explicitly so error paths stay simple C-style).

@@ -441,24 +441,33 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     const void *lut_f = (const char *)b->lut.p + 256 * sizeof(double);
     const int passes = b->precision == AGX_PHMM_F32 ? 2 : 1;
     if (passes == 2) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
-    for (int pass = 0; pass < passes; ++pass) {
-        // F32: pass 0 = float fill, pass 1 = double recomputation of the pairs that underflowed
-        int mode = b->precision;
-        if (b->probs) mode = 4;
-        if (pass == 1) mode = 3;
-        for (const ClassLaunch &cl : b->launches) {
+    // the counter reset above is ordered before the fork; each class's fill and (F32) its double
+    // rescue pass share a stream, different classes run side by side
+    FanOut fan(b->ctx, (int)b->launches.size());
+    rc = fan.begin();
+    if (rc) return rc;
+    int k = 0;
+    for (const ClassLaunch &cl : b->launches) {
+        hipStream_t st = fan.stream(k++);
+        for (int pass = 0; pass < passes; ++pass) {
+            // F32: pass 0 = float fill, pass 1 = double recomputation of the pairs that underflowed
+            int mode = b->precision;
+            if (b->probs) mode = 4;
+            if (pass == 1) mode = 3;
             const bool f64 = mode != 2;
             const size_t lds = pass == 1 ? cl.lds_rescue : cl.lds; // same records, wider table rows
             const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->groups.p,
                                                 (const PhTab *)b->tabs.p, (const PhWave *)b->waves.p + cl.first_wave,
                                                 cl.n_waves, f64 ? lut_d : lut_f, (double *)b->sums.p,
-                                                (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, s);
+                                                (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, st);
             if (r) {
                 agx_set_error("phmm_fill<C=%d, mode %d> launch failed: %s", cl.C, mode, hipGetErrorString(hipGetLastError()));
                 return AGX_E_HIP;
             }
         }
     }
+    rc = fan.end();
+    if (rc) return rc;
     return AGX_OK;
 }
 

@@ -11,6 +11,42 @@ extern "C" void agx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+int FanOut::begin()
+{
+    if (n <= 1) return AGX_OK;
+    if (!c->fork) {
+        AGX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+        for (int k = 0; k < kAuxStreams; ++k) {
+            AGX_HIP(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+            AGX_HIP(hipEventCreateWithFlags(&c->join[k], hipEventDisableTiming));
+        }
+    }
+    AGX_HIP(hipEventRecord(c->fork, c->stream));
+    return AGX_OK;
+}
+
+hipStream_t FanOut::stream(int k)
+{
+    if (n <= 1) return c->stream;
+    const int lane = k % (kAuxStreams + 1);
+    if (lane == 0) return c->stream;
+    if (!used[lane - 1]) {
+        (void)hipStreamWaitEvent(c->aux[lane - 1], c->fork, 0);
+        used[lane - 1] = true;
+    }
+    return c->aux[lane - 1];
+}
+
+int FanOut::end()
+{
+    for (int k = 0; k < kAuxStreams; ++k)
+        if (used[k]) {
+            AGX_HIP(hipEventRecord(c->join[k], c->aux[k]));
+            AGX_HIP(hipStreamWaitEvent(c->stream, c->join[k], 0));
+        }
+    return AGX_OK;
+}
+
 extern "C" {
 
 const char *agx_version(void) { return "agx 0.1 (gfx950)"; }
@@ -83,6 +119,11 @@ void agx_ctx_destroy(agx_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (int k = 0; k < kAuxStreams; ++k) {
+        if (c->join[k]) (void)hipEventDestroy(c->join[k]);
+        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

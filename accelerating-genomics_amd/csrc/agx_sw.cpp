@@ -446,20 +446,25 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
+    FanOut fan(b->ctx, (int)b->launches.size());
+    rc = fan.begin();
+    if (rc) return rc;
+    int k = 0;
     for (const ClassLaunch &cl : b->launches) {
+        hipStream_t st = fan.stream(k++);
         const int r = b->packed
                           ? agx_sw_pk_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                                   (int32_t *)b->scores.p, b->ctx->stream)
+                                                   (int32_t *)b->scores.p, st)
                           : agx_sw_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
                                                 (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                                (int32_t *)b->scores.p, b->ctx->stream);
+                                                (int32_t *)b->scores.p, st);
         if (r) {
             agx_set_error("sw_fill<%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }
     }
-    return AGX_OK;
+    return fan.end();
 }
 
 int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
