@@ -213,7 +213,7 @@ def main():
             "log10_checksum": float(ph_l.sum()),
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
         out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
         out["pairhmm"]["cpu_baseline"] = cpu_baseline_phmm(max(1, args.cpu_sample_pairs // (PH_READS * PH_HAPS)))
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
