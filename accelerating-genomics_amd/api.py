@@ -187,13 +187,14 @@ class Context:
 
 
 class SwBatch:
-    """agx_sw_batch: a scheduled batch resident in HBM."""
+    """agx_sw_batch: a scheduled batch resident in HBM (ctx=None: planned on the host only)."""
 
-    def __init__(self, ctx: Context, b):
+    def __init__(self, ctx, b):
         self.ctx = ctx
         self.n_pairs = b.n_pairs
         self._h = C.c_void_p()
-        _check(lib().agx_sw_batch_create(ctx._h, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs, C.byref(self._h)))
+        _check(lib().agx_sw_batch_create(ctx._h if ctx else None, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs,
+                                         C.byref(self._h)))
 
     def launch(self):
         _check(lib().agx_sw_batch_launch(self._h))
@@ -234,12 +235,12 @@ def phmm_desc(b):
 class PhmmBatchDev:
     """agx_phmm_batch: a scheduled PairHMM batch resident in HBM."""
 
-    def __init__(self, ctx: Context, b, precision=PHMM_F64):
+    def __init__(self, ctx, b, precision=PHMM_F64):
         self.ctx = ctx
         self.n_pairs = b.n_pairs
         self._h = C.c_void_p()
         d, self._keep = phmm_desc(b)
-        _check(lib().agx_phmm_batch_create(ctx._h, C.byref(d), precision, C.byref(self._h)))
+        _check(lib().agx_phmm_batch_create(ctx._h if ctx else None, C.byref(d), precision, C.byref(self._h)))
 
     def launch(self):
         _check(lib().agx_phmm_batch_launch(self._h))

@@ -139,8 +139,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         return AGX_E_ARG;
     }
     *out = nullptr;
-    int rc = agx_bind(ctx);
+    // ctx == NULL: plan only (no device needed) -- the batch answers agx_phmm_batch_info() and nothing else
+    int rc = ctx ? agx_bind(ctx) : AGX_OK;
     if (rc) return rc;
+    const int n_cu = ctx ? ctx->n_cu : 256;
     if (!d || precision < AGX_PHMM_F64 || precision > AGX_PHMM_F32) {
         agx_set_error("agx_phmm_batch_create: bad descriptor or precision %d", precision);
         return AGX_E_ARG;
@@ -208,7 +210,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         }
     }
     // dominant (R, H) shape?
-    if (gen.size() >= 1024 && ctx->n_cu > 0) {
+    if (gen.size() >= 1024 && n_cu > 0) {
         const size_t stride = gen.size() / 512;
         uint32_t cand = 0;
         int votes = 0;
@@ -226,7 +228,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             if ((p.R << 16 | p.H) == cand) ++count;
         if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
             uint8_t c = 255, G = 0;
-            choose_tiling_uniform(precision, cand >> 16, cand & 0xffffu, count, 4 * ctx->n_cu, &c, &G);
+            choose_tiling_uniform(precision, cand >> 16, cand & 0xffffu, count, 4 * n_cu, &c, &G);
             if (c < kPhNumClasses)
                 for (Plan &p : gen)
                     if ((p.R << 16 | p.H) == cand) {
@@ -367,6 +369,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                                     waves.size() * sizeof(PhWave));
     b->info.n_launches = (int32_t)launches.size() * (precision == AGX_PHMM_F32 ? 2 : 1);
     b->info.n_waves = (int32_t)waves.size();
+    if (!ctx) { // planning only
+        *out = b;
+        return AGX_OK;
+    }
     double lut_d[256];
     float lut_f[256];
     build_lut(lut_d, lut_f);
@@ -434,6 +440,10 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         agx_set_error("agx_phmm_batch_launch: null batch");
         return AGX_E_ARG;
     }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device): it cannot be launched");
+        return AGX_E_NODEVICE;
+    }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
     hipStream_t s = b->ctx->stream;
@@ -476,6 +486,10 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     if (!b || (!log10_lik && b->n_pairs)) {
         agx_set_error("agx_phmm_batch_results: null argument");
         return AGX_E_ARG;
+    }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device): it has no results");
+        return AGX_E_NODEVICE;
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;

@@ -150,8 +150,10 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         return AGX_E_ARG;
     }
     *out = nullptr;
-    int rc = agx_bind(ctx);
+    // ctx == NULL: plan only (no device needed) -- the batch answers agx_sw_batch_info() and nothing else
+    int rc = ctx ? agx_bind(ctx) : AGX_OK;
     if (rc) return rc;
+    const int n_cu = ctx ? ctx->n_cu : 256;
     if (n_pairs < 0 || (n_pairs > 0 && (!off || !len))) {
         agx_set_error("agx_sw_batch_create: bad arguments (n_pairs=%lld)", (long long)n_pairs);
         return AGX_E_ARG;
@@ -227,7 +229,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             return w.rc;
         }
     // dominant shape?  (sampled first, counted only if the sample says so)
-    if (n_pairs >= 1024 && ctx->n_cu > 0) {
+    if (n_pairs >= 1024 && n_cu > 0) {
         const size_t stride = (size_t)n_pairs / 512;
         uint32_t cand = 0;
         int votes = 0;
@@ -246,7 +248,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             for (const PairPlan &pp : all)
                 if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) ++count;
         if (count * 2 >= n_pairs) {
-            const Tiling tl = choose_tiling_uniform((int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * ctx->n_cu);
+            const Tiling tl = choose_tiling_uniform((int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * n_cu);
             if (tl.cls >= 0)
                 for (PairPlan &pp : all)
                     if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) {
@@ -410,6 +412,10 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
     b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
     b->info.n_launches = (int32_t)launches.size();
     b->info.n_waves = (int32_t)waves.size();
+    if (!ctx) { // planning only
+        *out = b;
+        return AGX_OK;
+    }
     rc = b->img.alloc(img.size() * 4);
     if (!rc) rc = b->groups.alloc(groups_bytes);
     if (!rc) rc = b->waves.alloc(waves.size() * sizeof(SwWave));
@@ -444,6 +450,10 @@ int agx_sw_batch_launch(agx_sw_batch *b)
         agx_set_error("agx_sw_batch_launch: null batch");
         return AGX_E_ARG;
     }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device): it cannot be launched");
+        return AGX_E_NODEVICE;
+    }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
     FanOut fan(b->ctx, (int)b->launches.size());
@@ -472,6 +482,10 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
     if (!b || (!scores && b->n_pairs)) {
         agx_set_error("agx_sw_batch_scores: null argument");
         return AGX_E_ARG;
+    }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device): it has no scores");
+        return AGX_E_NODEVICE;
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;

@@ -95,7 +95,9 @@ typedef struct agx_sw_info {
     int32_t n_waves;      /* wavefronts over all launches */
 } agx_sw_info;
 
-/* Validate, pick the lane tiling per pair, pack and copy to the device.  Blocking. */
+/* Validate, pick the lane tiling per pair, pack and copy to the device.  Blocking.
+ * ctx may be NULL: the batch is then only planned on the host (no device needed); it answers
+ * agx_sw_batch_info() and every other call on it fails with AGX_E_NODEVICE. */
 int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
                         int64_t n_pairs, agx_sw_batch **out);
 /* Enqueue the fill on the context's stream; scores stay in HBM.  Asynchronous. */
@@ -158,6 +160,7 @@ typedef struct agx_phmm_info {
     int64_t n_rescued;    /* F32 only: pairs recomputed in double by the last launch+results */
 } agx_phmm_info;
 
+/* ctx may be NULL: plan only, as for agx_sw_batch_create. */
 int agx_phmm_batch_create(agx_ctx *ctx, const agx_phmm_desc *d, int precision, agx_phmm_batch **out);
 int agx_phmm_batch_launch(agx_phmm_batch *b);
 /* log10_lik[k] = log10(sum_k) - log10(C), C = DBL_MAX/16 (FLT_MAX/16 for F32), both log10 taken by the

@@ -1,0 +1,72 @@
+"""Host logic without a device: agx_*_batch_create(ctx=NULL) plans a batch (validation, lane tiling,
+wave formation, packing) and reports what it would launch."""
+import numpy as np
+import pytest
+
+import accelerating_genomics_amd.api as agx
+import accelerating_genomics_amd.synth as synth
+
+
+def plan_sw(b):
+    p = agx.SwBatch(None, b)
+    i = p.info()
+    out = dict(n_pairs=i.n_pairs, cells=i.cells, padded=i.padded_cells, launches=i.n_launches, waves=i.n_waves, bytes=i.input_bytes)
+    p.close()
+    return out
+
+
+def test_config2_plan_is_one_launch_of_38_column_lanes():
+    b = synth.sw_pairs(65536, 150, 150, seed=2)
+    i = plan_sw(b)
+    assert i["n_pairs"] == 65536 and i["cells"] == b.cells() == 65536 * 151 * 151
+    assert i["launches"] == 1 and i["waves"] == 2048  # G=4 lanes x 38 columns, 16 groups x 2 pairs per wave
+    assert i["cells"] / i["padded"] > 0.97
+    assert i["bytes"] < 1.15 * b.algorithmic_bytes()  # packed image + records stay close to the algorithmic bytes
+
+
+def test_mixed_lengths_plan_covers_every_pair_with_little_padding():
+    b = synth.sw_pairs(50000, 32, 512, seed=4)
+    i = plan_sw(b)
+    assert i["cells"] == b.cells() and i["padded"] >= i["cells"]
+    assert i["cells"] / i["padded"] > 0.90 and 1 <= i["launches"] <= 19
+
+
+def test_degenerate_batches_plan():
+    assert plan_sw(synth.sw_from_seqs([]))["waves"] == 0
+    i = plan_sw(synth.sw_from_seqs([b"", b"ACGT", b"A", b"C"]))
+    assert i["n_pairs"] == 2 and i["waves"] == 1 and i["cells"] == 1
+
+
+def test_validation_errors_need_no_device():
+    with pytest.raises(agx.AgxError) as e:
+        plan_sw(synth.sw_from_seqs([b"AC\x00GT", b"ACGT"]))
+    assert e.value.code == agx.E_SYMBOL
+    with pytest.raises(agx.AgxError) as e:
+        plan_sw(synth.sw_from_seqs([b"A" * 2561, b"C" * 2561]))
+    assert e.value.code == agx.E_LIMIT
+    plan_sw(synth.sw_from_seqs([b"A" * 2560, b"C" * 60000]))  # the limits themselves are fine
+
+
+def test_planned_batch_cannot_run():
+    p = agx.SwBatch(None, synth.sw_pairs(4, 10, 20, seed=1))
+    with pytest.raises(agx.AgxError) as e:
+        p.launch()
+    assert e.value.code == agx.E_NODEVICE
+    with pytest.raises(agx.AgxError):
+        p.scores()
+
+
+@pytest.mark.parametrize("prec", [agx.PHMM_F64, agx.PHMM_F64_FMA, agx.PHMM_F32])
+def test_phmm_plans(prec):
+    b = synth.phmm_regions(64, 64, 16, 100, 300, seed=3)
+    p = agx.PhmmBatchDev(None, b, prec)
+    i = p.info()
+    assert i.n_pairs == 65536 and i.cells == b.cells() and i.padded_cells >= i.cells
+    assert i.cells / i.padded_cells > (0.90 if prec == agx.PHMM_F32 else 0.80)
+    assert i.n_launches == (2 if prec == agx.PHMM_F32 else 1)
+    with pytest.raises(agx.AgxError):
+        p.launch()
+    p.close()
+    with pytest.raises(agx.AgxError) as e:
+        agx.PhmmBatchDev(None, synth.phmm_regions(1, 1, 1, 10, 2100, seed=1), prec)
+    assert e.value.code == agx.E_LIMIT

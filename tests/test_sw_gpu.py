@@ -126,3 +126,20 @@ def test_full_size_config4_mixed_lengths(ctx, oracle):
                        b.len[:131072].reshape(-1, 2)[:, ::-1].reshape(-1).copy())
     assert np.array_equal(ctx.sw_score(sl), got[:65536])
     assert got.min() >= 0 and got.max() <= 513
+
+
+def test_external_stream_from_torch(oracle):
+    """A host that owns a HIP stream (here: PyTorch) installs it with agx_ctx_set_stream; launches then
+    order with that stream's other work and torch.cuda.synchronize() covers them."""
+    torch = pytest.importorskip("torch")
+    st = torch.cuda.Stream()
+    b = synth.sw_pairs(4096, 50, 300, seed=21, related_frac=0.5)
+    with agx.Context(0) as c:
+        c.set_stream(st.cuda_stream)
+        assert c.stream == st.cuda_stream
+        dev = c.sw_batch(b)
+        with torch.cuda.stream(st):
+            dev.launch()
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.scores(), oracle.sw_batch(b))
+        dev.close()
