@@ -128,18 +128,33 @@ def test_full_size_config4_mixed_lengths(ctx, oracle):
     assert got.min() >= 0 and got.max() <= 513
 
 
-def test_external_stream_from_torch(oracle):
+def test_external_stream_from_torch(tmp_path):
     """A host that owns a HIP stream (here: PyTorch) installs it with agx_ctx_set_stream; launches then
-    order with that stream's other work and torch.cuda.synchronize() covers them."""
-    torch = pytest.importorskip("torch")
-    st = torch.cuda.Stream()
-    b = synth.sw_pairs(4096, 50, 300, seed=21, related_frac=0.5)
-    with agx.Context(0) as c:
-        c.set_stream(st.cuda_stream)
-        assert c.stream == st.cuda_stream
-        dev = c.sw_batch(b)
-        with torch.cuda.stream(st):
-            dev.launch()
-        torch.cuda.synchronize()
-        assert np.array_equal(dev.scores(), oracle.sw_batch(b))
-        dev.close()
+    order with that stream's other work and torch.cuda.synchronize() covers them.  Runs in its own
+    process with torch initialised first, as a torch host would (torch ships its own HIP runtime;
+    whichever runtime a process loads first is the one every library in it must share)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import torch
+        st = torch.cuda.Stream()
+        import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+        from tests import oracle_api
+        b = synth.sw_pairs(4096, 50, 300, seed=21, related_frac=0.5)
+        with agx.Context(0) as c:
+            c.set_stream(st.cuda_stream)
+            assert c.stream == st.cuda_stream
+            dev = c.sw_batch(b)
+            with torch.cuda.stream(st):
+                dev.launch()
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.scores(), oracle_api.load().sw_batch(b))
+            dev.close()
+        print("STREAM_OK")
+    """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300)
+    assert r.returncode == 0 and b"STREAM_OK" in r.stdout, r.stderr.decode()[-1500:]
