@@ -5,7 +5,7 @@
 //
 // Why: on gfx950 v_max_i32 / v_max3_i32 / v_cndmask issue at about half the rate of v_add_u32,
 // and one packed instruction costs the same issue slot as one of those slow ones while doing two
-// cells (tools/valu_microbench.hip, profiles/r01_valu_microbench.log).  13 packed instructions per
+// cells (tools/valu_microbench.hip, profiles/r01_valu_microbench.log).  12 packed instructions per
 // 2 cells replace 2 x 10.5 scalar ones.
 //
 // Exactness: scores are bounded by the shorter length (<= 2560 < 32767) and the gap states by
@@ -122,8 +122,11 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
             f = pmax(zleft, f + splat(-1));                 // reference Q, :321
             const u16x2 d = __builtin_bit_cast(u16x2, xq[j] ^ yc);
             const u16x2 m2 = __builtin_elementwise_min(d, u16x2{2, 2}); // 0 on a match, 2 otherwise
-            const s16x2 s = (zd + splat(5)) - __builtin_bit_cast(s16x2, m2); // H_diag +1 / -1, :332
-            const s16x2 v = pmax(pmax(ev, f), pmax(s, splat(0)));     // :333
+            // H_diag + 1 >= 1 as an unsigned value; the saturating subtract of 0 / 2 yields
+            // max(H_diag +1 / -1, 0): the diagonal move (:332) and the zero floor of :333 in one go
+            const u16x2 hd1 = __builtin_bit_cast(u16x2, zd + splat(5));
+            const s16x2 s = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(hd1, m2));
+            const s16x2 v = pmax(pmax(ev, f), s); // :333 (e, f may be negative, s carries the floor)
             const s16x2 zn = v + splat(-4);
             e[j] = ev;
             z[j] = zn;

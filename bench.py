@@ -198,8 +198,8 @@ def main():
         "roofline": roof(sw_bytes, sw_launch_ms, "sw_fill"),
         "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
                "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
-               "valu": {"ops_per_cell": "13 packed int16 instructions per 2 cells (v_pk_add/max/min/sub_i16 + xor)",
-                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (6.5 / VALU_PACKED) / (sw_launch_ms * 1e-3)},
+               "valu": {"ops_per_cell": "12 packed int16 instructions per 2 cells (v_pk_add/max/min_u16/sub_u16 clamp + xor)",
+                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (6.0 / VALU_PACKED) / (sw_launch_ms * 1e-3)},
                "score_checksum": int(sw_scores.astype(np.int64).sum())},
         "pairhmm": {
             "metric": "PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)",
