@@ -210,3 +210,17 @@ def test_full_size_config5_fp64(ctx, oracle):
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), got) <= 1e-12
     rev = synth.phmm_from_regions(_as_regions(b)[::-1])
     assert np.array_equal(ctx.phmm_forward(rev, agx.PHMM_F64).reshape(512, -1)[::-1].reshape(-1), got)
+
+
+def test_largest_supported_shapes(ctx, oracle):
+    """R = 4096 needs a 139 KB read table (most of the 160 KB LDS); H = 2048 spans 64 lanes x 32 columns."""
+    b = synth.phmm_regions(1, 2, 2, 4096, 2048, seed=77)
+    s_ref, l_ref = oracle.phmm_batch(b, 0)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64)
+    dev.launch()
+    l, s = dev.results()
+    assert np.array_equal(s, s_ref)
+    dev.close()
+    got32 = ctx.phmm_forward(b, agx.PHMM_F32)
+    assert relerr(got32, l_ref) <= 1e-6
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), l_ref) <= 1e-12

@@ -158,3 +158,16 @@ def test_external_stream_from_torch(tmp_path):
     """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300)
     assert r.returncode == 0 and b"STREAM_OK" in r.stdout, r.stderr.decode()[-1500:]
+
+
+def test_largest_supported_shapes(ctx, oracle):
+    """shorter side 2560 = 64 lanes x 40 columns; longer side up to 65 535 rows streams."""
+    rng = np.random.default_rng(31)
+    a = bytes(rng.choice(list(b"ACGT"), size=2560).tolist())
+    y = bytearray(rng.choice(list(b"ACGT"), size=65535).tolist())
+    y[30000:32560] = a  # a full-length hit in the middle
+    y[31000] = ord("N")
+    b = synth.sw_from_seqs([a, bytes(y), bytes(y[:3000]), a[:2000]])
+    got = ctx.sw_score(b)
+    assert np.array_equal(got, oracle.sw_batch(b))
+    assert got[0] >= 2550
