@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=32768)
+    # rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (never for numbers):
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--share-device", action="store_true", help="map every rank to device 0")
     args = ap.parse_args()
 
     import torch
@@ -120,10 +123,16 @@ def main():
     multi = world > 1
     if agx.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; libagx has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world if multi else 1
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE %d; reporting n_gpus=%d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -147,7 +156,7 @@ def main():
         ev_ms = ctx.timer_stop()  # HIP events on the launch stream (also drains it)
         barrier()
         dt = time.perf_counter() - t0
-        return agd.max_over_ranks(dt, device="cuda"), ev_ms / args.steps
+        return agd.max_over_ranks(dt, device=red_dev), ev_ms / args.steps
 
     # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
     sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
