@@ -18,7 +18,7 @@ PHMM_F64, PHMM_F64_FMA, PHMM_F32 = 0, 1, 2
 SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
     "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_timer_start", "agx_ctx_timer_stop",
-    "agx_sw_batch_create", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
+    "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi",
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
     "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_pairHMM",
@@ -35,6 +35,10 @@ class AgxError(RuntimeError):
 class SwInfo(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("cells", C.c_int64), ("padded_cells", C.c_int64), ("input_bytes", C.c_int64),
                 ("n_launches", C.c_int32), ("n_waves", C.c_int32)]
+
+
+class SwScoring(C.Structure):
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
 
 
 class PhmmDesc(C.Structure):
@@ -86,6 +90,8 @@ def lib():
         l.agx_ctx_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.agx_sw_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.POINTER(C.c_void_p)]
+        l.agx_sw_batch_create_scored.argtypes = [C.c_void_p, C.POINTER(SwScoring), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int64, C.POINTER(C.c_void_p)]
         l.agx_sw_batch_launch.argtypes = [C.c_void_p]
         l.agx_sw_batch_scores.argtypes = [C.c_void_p, C.c_void_p]
         l.agx_sw_batch_info.argtypes = [C.c_void_p, C.POINTER(SwInfo)]
@@ -166,8 +172,8 @@ class Context:
         return ms.value
 
     # ---- Smith-Waterman
-    def sw_batch(self, b) -> "SwBatch":
-        return SwBatch(self, b)
+    def sw_batch(self, b, scoring=None) -> "SwBatch":
+        return SwBatch(self, b, scoring)
 
     def sw_score(self, b) -> np.ndarray:
         """b: synth.SWBatch (bases/off/len) -> int32 scores, one-shot."""
@@ -189,12 +195,14 @@ class Context:
 class SwBatch:
     """agx_sw_batch: a scheduled batch resident in HBM (ctx=None: planned on the host only)."""
 
-    def __init__(self, ctx, b):
+    def __init__(self, ctx, b, scoring=None):
+        """scoring: None (the reference's +1/-1/-3/-1) or (match, mismatch, gap_open, gap_extend)."""
         self.ctx = ctx
         self.n_pairs = b.n_pairs
         self._h = C.c_void_p()
-        _check(lib().agx_sw_batch_create(ctx._h if ctx else None, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs,
-                                         C.byref(self._h)))
+        sc = C.byref(SwScoring(*scoring)) if scoring is not None else None
+        _check(lib().agx_sw_batch_create_scored(ctx._h if ctx else None, sc, _ptr(b.bases), _ptr(b.off), _ptr(b.len),
+                                                b.n_pairs, C.byref(self._h)))
 
     def launch(self):
         _check(lib().agx_sw_batch_launch(self._h))

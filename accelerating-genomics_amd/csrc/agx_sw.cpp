@@ -123,6 +123,7 @@ struct ClassLaunch {
 struct agx_sw_batch {
     agx_ctx *ctx = nullptr;
     bool packed = false;
+    SwParams prm{};
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
     std::vector<ClassLaunch> launches;
@@ -145,6 +146,12 @@ void agx_sw_batch_destroy(agx_sw_batch *b)
 int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
                         agx_sw_batch **out)
 {
+    return agx_sw_batch_create_scored(ctx, nullptr, bases, off, len, n_pairs, out);
+}
+
+int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, const uint8_t *bases, const uint64_t *off,
+                               const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
+{
     if (!out) {
         agx_set_error("agx_sw_batch_create: out is NULL");
         return AGX_E_ARG;
@@ -162,6 +169,31 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
         agx_set_error("agx_sw_batch_create: more than 2^30 pairs in one batch");
         return AGX_E_LIMIT;
     }
+
+    // ---- scoring -> kernel constants
+    const agx_sw_scoring ref_scoring = AGX_SW_SCORING_REFERENCE;
+    const agx_sw_scoring sc = scoring ? *scoring : ref_scoring;
+    // mismatch <= 0: padding relies on never-matching symbols not raising a score
+    if (sc.match < 1 || sc.match > 12 || sc.mismatch > 0 || sc.mismatch < sc.match - 128 || sc.gap_open > 0 ||
+        sc.gap_open < -1000 || sc.gap_extend > 0 || sc.gap_extend < -1000) {
+        agx_set_error("scoring {match %d, mismatch %d, open %d, extend %d} outside the supported range", sc.match,
+                      sc.mismatch, sc.gap_open, sc.gap_extend);
+        return AGX_E_LIMIT;
+    }
+    SwParams prm{};
+    prm.ge = sc.gap_extend;
+    prm.gf = sc.gap_open + sc.gap_extend;
+    prm.hd = sc.match - prm.gf;
+    prm.delta = sc.match - sc.mismatch;
+    prm.shift = 0;
+    while ((1 << prm.shift) < prm.delta) ++prm.shift;
+    auto twice = [](int v) { return (uint32_t)(uint16_t)(int16_t)v * 0x10001u; };
+    prm.ge2 = twice(prm.ge);
+    prm.gf2 = twice(prm.gf);
+    prm.hd2 = twice(prm.hd);
+    prm.delta2 = twice(prm.delta);
+    prm.zero_score2 = twice(prm.gf);
+    const uint32_t max_short = std::min<uint32_t>(AGX_SW_MAX_SHORT_LEN, 32000u / (uint32_t)sc.match);
 
     const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -196,7 +228,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             const uint32_t lx = second_short ? lb : la, ly = second_short ? la : lb;
             int rc = AGX_OK;
             Tiling tl{-1, 0};
-            if (lx > AGX_SW_MAX_SHORT_LEN || ly > 0xffffu) rc = AGX_E_LIMIT;
+            if (lx > max_short || ly > 0xffffu) rc = AGX_E_LIMIT;
             else if (memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb)) rc = AGX_E_SYMBOL;
             else {
                 tl = choose_tiling((int)lx, (int)ly);
@@ -224,8 +256,8 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
             if (w.rc == AGX_E_SYMBOL)
                 agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)p);
             else
-                agx_set_error("pair %lld: lengths %u x %u exceed the supported %d x 65535 (shorter x longer)", (long long)p,
-                              len[2 * p], len[2 * p + 1], AGX_SW_MAX_SHORT_LEN);
+                agx_set_error("pair %lld: lengths %u x %u exceed the supported %u x 65535 (shorter x longer)", (long long)p,
+                              len[2 * p], len[2 * p + 1], max_short);
             return w.rc;
         }
     // dominant shape?  (sampled first, counted only if the sample says so)
@@ -409,6 +441,7 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
     b->info.cells = cells;
     b->info.padded_cells = padded;
     b->packed = packed;
+    b->prm = prm;
     b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
     b->info.n_launches = (int32_t)launches.size();
     b->info.n_waves = (int32_t)waves.size();
@@ -463,10 +496,10 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     for (const ClassLaunch &cl : b->launches) {
         hipStream_t st = fan.stream(k++);
         const int r = b->packed
-                          ? agx_sw_pk_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
+                          ? agx_sw_pk_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                    (int32_t *)b->scores.p, st)
-                          : agx_sw_launch_class(cl.C, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
+                          : agx_sw_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
                                                 (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                 (int32_t *)b->scores.p, st);
         if (r) {

@@ -14,6 +14,19 @@ struct SwGroup {
     uint32_t out;   // index into scores[]
 };
 
+// Scoring, as the kernels consume it (built by the host from agx_sw_scoring).  With z = H + gf the
+// state both gap recurrences read, a cell is  e = max(z_up, e + ge),  f = max(z_left, f + ge),
+// s = H_diag + match - {0, delta},  H = max(e, f, s, 0),  z = H + gf.
+struct SwParams {
+    int32_t ge;      // gap extend (<= 0): every further gap cell
+    int32_t gf;      // first gap cell = open + extend (<= 0)
+    int32_t hd;      // match - gf: turns z_diag into H_diag + match
+    int32_t delta;   // match - mismatch (> 0)
+    int32_t shift;   // packed kernel: symbols are compared as byte << shift, 2^shift >= delta
+    // the same, replicated into both 16-bit halves for the packed kernel
+    uint32_t ge2, gf2, hd2, delta2, zero_score2;
+};
+
 // Packed kernel: one group of G lanes carries two pairs (index 0 = low 16 bits, 1 = high 16 bits
 // of every state register).  A group without a second pair points [1] at an all-zero sequence
 // of length 0 and at the spare score slot scores[n_pairs].
@@ -47,7 +60,7 @@ static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 
 // same for the packed int16 kernel
 static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000};
 
-int agx_sw_pk_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves,
-                           uint32_t n_waves, int32_t *scores, hipStream_t s);
-int agx_sw_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup *groups, const SwWave *waves,
-                        uint32_t n_waves, int32_t *scores, hipStream_t s);
+int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+                           const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
+int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
+                        const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);

@@ -53,11 +53,13 @@ __device__ __forceinline__ int shr1(int old, int v)
 }
 
 template <int C>
-__global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img, const SwGroup *__restrict__ groups,
+__global__ void __launch_bounds__(256) sw_fill(const SwParams prm, const uint32_t *__restrict__ img,
+                                               const SwGroup *__restrict__ groups,
                                                const SwWave *__restrict__ waves, uint32_t n_waves,
                                                int32_t *__restrict__ scores)
 {
     constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
+    const int ge = prm.ge, gf = prm.gf, s_match = prm.hd, s_mis = prm.hd - prm.delta;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & 63;
@@ -95,10 +97,10 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
     int z[C], e[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        z[j] = -4;
+        z[j] = gf;
         e[j] = kNegInf;
     }
-    int z_last = -4, f_last = kNegInf, diag_in = -4, best = -4;
+    int z_last = gf, f_last = kNegInf, diag_in = gf, best = gf;
     int yc_prev = (int)kRowPad;
 
     uint32_t q0 = row_quad(0), q1 = row_quad(1), q2 = row_quad(2);
@@ -110,11 +112,11 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
     auto step = [&]() __attribute__((always_inline)) {
         const int fresh = (t < ly) ? (int)(rows & 0xffu) : (int)kRowPad;
         rows >>= 8;
-        int zl = shr1(-4, z_last);
+        int zl = shr1(gf, z_last);
         int fl = shr1(kNegInf, f_last);
         int yc = shr1(fresh, yc_prev);
         if (start) { // column 0: H = 0, Q = -inf (antidiagonalSmithWaterman.c:299-306)
-            zl = -4;
+            zl = gf;
             fl = kNegInf;
             yc = fresh;
         }
@@ -125,11 +127,11 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
         for (int j = 0; j < C; ++j) {
             const int xs = (int)((xw[j >> 2] >> (8 * (j & 3))) & 0xffu);
             const int up = z[j];
-            const int ev = max(up, e[j] - 1);         // reference P, :313
-            f = max(zleft, f - 1);                    // reference Q, :321
-            const int s = zd + (xs == yc ? 5 : 3);    // H_diag +1 / -1, :332
-            const int v = max(max(ev, f), max(s, 0)); // :333
-            const int zn = v - 4;
+            const int ev = max(up, e[j] + ge);              // reference P, :313
+            f = max(zleft, f + ge);                         // reference Q, :321
+            const int s = zd + (xs == yc ? s_match : s_mis); // H_diag + match / + mismatch, :332
+            const int v = max(max(ev, f), max(s, 0));       // :333
+            const int zn = v + gf;
             e[j] = ev;
             z[j] = zn;
             zd = up;
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
 #pragma unroll 1
     while (t < steps) step(); // 0..3 remaining rows
 
-    best += 4;
+    best -= gf;
 
     // max over the group's lanes (G need not be a power of two)
     for (int o = 1; o < G; o <<= 1) {
@@ -170,23 +172,23 @@ __global__ void __launch_bounds__(256) sw_fill(const uint32_t *__restrict__ img,
 }
 
 template <int C>
-int launch(const uint32_t *img, const SwGroup *groups, const SwWave *waves, uint32_t n_waves, int32_t *scores,
-           hipStream_t s)
+int launch(const SwParams &prm, const uint32_t *img, const SwGroup *groups, const SwWave *waves, uint32_t n_waves,
+           int32_t *scores, hipStream_t s)
 {
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(sw_fill<C>, dim3(blocks), dim3(256), 0, s, img, groups, waves, n_waves, scores);
+    hipLaunchKernelGGL(sw_fill<C>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 } // namespace
 
-int agx_sw_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup *groups, const SwWave *waves,
-                        uint32_t n_waves, int32_t *scores, hipStream_t s)
+int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
+                        const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_SW_CASE(CC) \
-    case CC: return launch<CC>(img, groups, waves, n_waves, scores, s);
+    case CC: return launch<CC>(prm, img, groups, waves, n_waves, scores, s);
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: return -2;

@@ -11,8 +11,9 @@
 // Exactness: scores are bounded by the shorter length (<= 2560 < 32767) and the gap states by
 // -4 and the -inf stand-in, so int16 lanes hold every value of the reference recurrence
 // (antidiagonalSmithWaterman.c:313,:321,:332-335) without wrap-around; results are bit-identical
-// to the int32 kernel.  Symbols are compared as (byte << 1): x ^ y is then 0 on a match and >= 2
-// otherwise, so min(x ^ y, 2) is 0 / 2 = the score difference between match and mismatch.
+// to the int32 kernel.  Symbols are compared as (byte << shift): x ^ y is then 0 on a match and
+// >= 2^shift >= delta otherwise, so min(x ^ y, delta) is 0 / delta = match - mismatch (2 with the
+// reference's +1 / -1).  Scoring constants arrive as kernel arguments (SGPR operands).
 #include "agx_sw.h"
 
 namespace {
@@ -20,8 +21,7 @@ namespace {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-constexpr short kNeg16 = -16000;     // -inf stand-in; never decremented more than once before a max
-constexpr uint32_t kRowPad16 = 0x200; // (0x100 << 1): never equals (byte << 1)
+constexpr short kNeg16 = -16000; // -inf stand-in; never decremented more than once before a max
 
 __device__ __forceinline__ s16x2 splat(short v) { return s16x2{v, v}; }
 __device__ __forceinline__ s16x2 as_s(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
@@ -34,11 +34,16 @@ __device__ __forceinline__ uint32_t shr1u(uint32_t old, uint32_t v)
 }
 
 template <int C>
-__global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
+__global__ void __launch_bounds__(256) sw_fill_pk(const SwParams prm, const uint32_t *__restrict__ img,
+                                                  const SwGroup2 *__restrict__ groups,
                                                   const SwWave *__restrict__ waves, uint32_t n_waves,
                                                   int32_t *__restrict__ scores)
 {
     constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
+    const int sh_sym = prm.shift;                         // symbols live as byte << shift
+    const uint32_t row_pad = 0x100u << sh_sym;            // never equals (byte << shift)
+    const s16x2 ge = as_s(prm.ge2), gf = as_s(prm.gf2), hd = as_s(prm.hd2);
+    const u16x2 delta = __builtin_bit_cast(u16x2, prm.delta2);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
     const int lane = threadIdx.x & 63;
@@ -74,7 +79,8 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
             const uint32_t b = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (4 * k + i < C) xq[4 * k + i] = (((a >> (8 * i)) & 0xffu) << 1) | (((b >> (8 * i)) & 0xffu) << 17);
+                if (4 * k + i < C)
+                    xq[4 * k + i] = ((((a >> (8 * i)) & 0xffu) << sh_sym) | ((((b >> (8 * i)) & 0xffu) << sh_sym) << 16));
         }
     }
 
@@ -86,11 +92,11 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
     s16x2 z[C], e[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        z[j] = splat(-4);
+        z[j] = gf;
         e[j] = splat(kNeg16);
     }
-    s16x2 z_last = splat(-4), f_last = splat(kNeg16), diag_in = splat(-4), best = splat(-4);
-    uint32_t yc_prev = kRowPad16 | (kRowPad16 << 16);
+    s16x2 z_last = gf, f_last = splat(kNeg16), diag_in = gf, best = gf;
+    uint32_t yc_prev = row_pad | (row_pad << 16);
 
     uint32_t a0 = quadA(0), a1 = quadA(1), a2 = quadA(2);
     uint32_t b0 = quadB(0), b1 = quadB(1), b2 = quadB(2);
@@ -99,8 +105,8 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
     int t = 0;
 
     auto step = [&]() __attribute__((always_inline)) {
-        const uint32_t fa = (t < lyA) ? ((rowsA & 0xffu) << 1) : kRowPad16;
-        const uint32_t fb = (t < lyB) ? ((rowsB & 0xffu) << 1) : kRowPad16;
+        const uint32_t fa = (t < lyA) ? ((rowsA & 0xffu) << sh_sym) : row_pad;
+        const uint32_t fb = (t < lyB) ? ((rowsB & 0xffu) << sh_sym) : row_pad;
         rowsA >>= 8;
         rowsB >>= 8;
         const uint32_t fresh = fa | (fb << 16);
@@ -108,7 +114,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
         s16x2 fl = as_s(shr1u(0, as_u(f_last)));
         uint32_t yc = shr1u(fresh, yc_prev);
         if (start) { // column 0: H = 0, Q = -inf (antidiagonalSmithWaterman.c:299-306)
-            zl = splat(-4);
+            zl = gf;
             fl = splat(kNeg16);
             yc = fresh;
         }
@@ -118,16 +124,16 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             const s16x2 up = z[j];
-            const s16x2 ev = pmax(up, e[j] + splat(-1));   // reference P, :313
-            f = pmax(zleft, f + splat(-1));                 // reference Q, :321
+            const s16x2 ev = pmax(up, e[j] + ge); // reference P, :313
+            f = pmax(zleft, f + ge);              // reference Q, :321
             const u16x2 d = __builtin_bit_cast(u16x2, xq[j] ^ yc);
-            const u16x2 m2 = __builtin_elementwise_min(d, u16x2{2, 2}); // 0 on a match, 2 otherwise
-            // H_diag + 1 >= 1 as an unsigned value; the saturating subtract of 0 / 2 yields
-            // max(H_diag +1 / -1, 0): the diagonal move (:332) and the zero floor of :333 in one go
-            const u16x2 hd1 = __builtin_bit_cast(u16x2, zd + splat(5));
+            const u16x2 m2 = __builtin_elementwise_min(d, delta); // 0 on a match, match - mismatch otherwise
+            // H_diag + match >= 1 as an unsigned value; the saturating subtract of 0 / delta yields
+            // max(H_diag + match / + mismatch, 0): the diagonal move (:332) and the zero floor of :333 at once
+            const u16x2 hd1 = __builtin_bit_cast(u16x2, zd + hd);
             const s16x2 s = __builtin_bit_cast(s16x2, __builtin_elementwise_sub_sat(hd1, m2));
             const s16x2 v = pmax(pmax(ev, f), s); // :333 (e, f may be negative, s carries the floor)
-            const s16x2 zn = v + splat(-4);
+            const s16x2 zn = v + gf;
             e[j] = ev;
             z[j] = zn;
             zd = up;
@@ -164,29 +170,29 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const uint32_t *__restrict__ i
         if (gl + o < G) best = pmax(best, other);
     }
     if (feeder) {
-        scores[g.out[0]] = (int)best[0] + 4;
-        scores[g.out[1]] = (int)best[1] + 4; // a group without a second pair points this at the spare slot
+        scores[g.out[0]] = (int)best[0] - prm.gf;
+        scores[g.out[1]] = (int)best[1] - prm.gf; // a group without a second pair points this at the spare slot
     }
 }
 
 template <int C>
-int launch(const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves, int32_t *scores,
-           hipStream_t s)
+int launch(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+           int32_t *scores, hipStream_t s)
 {
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(sw_fill_pk<C>, dim3(blocks), dim3(256), 0, s, img, groups, waves, n_waves, scores);
+    hipLaunchKernelGGL(sw_fill_pk<C>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 } // namespace
 
-int agx_sw_pk_launch_class(int cols_per_lane, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves,
-                           uint32_t n_waves, int32_t *scores, hipStream_t s)
+int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+                           const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_SW_CASE(CC) \
-    case CC: return launch<CC>(img, groups, waves, n_waves, scores, s);
+    case CC: return launch<CC>(prm, img, groups, waves, n_waves, scores, s);
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: return -2;

@@ -95,11 +95,26 @@ typedef struct agx_sw_info {
     int32_t n_waves;      /* wavefronts over all launches */
 } agx_sw_info;
 
+/* Scoring of the fill (8f n3: the reference's GPU variants carry these as kernel arguments but
+ * ignore them, hipvers.cpp:214).  Values are ADDED to the score, as in the reference's macros
+ * (antidiagonalSmithWaterman.c:40-43): the first cell of a gap costs gap_open + gap_extend, every
+ * further one gap_extend.  Limits: 1 <= match <= 12, match - 128 <= mismatch <= 0,
+ * -1000 <= gap_open, gap_extend <= 0 (scores then fit the kernel's int16 lanes: 12 * 2560 < 32767). */
+typedef struct agx_sw_scoring {
+    int32_t match, mismatch, gap_open, gap_extend;
+} agx_sw_scoring;
+/* The reference's compile-time constants: +1, -1, -3, -1. */
+#define AGX_SW_SCORING_REFERENCE {1, -1, -3, -1}
+
 /* Validate, pick the lane tiling per pair, pack and copy to the device.  Blocking.
  * ctx may be NULL: the batch is then only planned on the host (no device needed); it answers
  * agx_sw_batch_info() and every other call on it fails with AGX_E_NODEVICE. */
 int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
                         int64_t n_pairs, agx_sw_batch **out);
+/* Same with caller-chosen scoring (NULL = the reference's).  Only the reference scoring is pinned
+ * against the reference program; other settings are checked against the oracle's parametrised Gotoh. */
+int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, const uint8_t *bases, const uint64_t *off,
+                               const uint32_t *len, int64_t n_pairs, agx_sw_batch **out);
 /* Enqueue the fill on the context's stream; scores stay in HBM.  Asynchronous. */
 int agx_sw_batch_launch(agx_sw_batch *b);
 /* Wait for the stream and copy the scores out in the caller's pair order. */

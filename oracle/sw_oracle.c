@@ -121,6 +121,50 @@ int oracle_sw_score_rowmajor(const unsigned char *sx, int lx, const unsigned cha
 }
 
 /*
+ * Parametrised Gotoh (runtime scoring parameters).  The reference has no such
+ * mode -- its kernel arguments are ignored (hipvers.cpp:214) -- so for settings other than
+ * (+1, -1, -3, -1) this is "parity unpinned": it pins the product against this restatement only.
+ * At the reference setting it is checked to equal oracle_sw_score_rowmajor (and thus the goldens).
+ * Values are added to the score; first gap cell = gap_open + gap_extend, further cells gap_extend.
+ */
+int oracle_sw_score_scored(const unsigned char *sx, int lx, const unsigned char *sy, int ly, int match, int mismatch,
+                           int gap_open, int gap_extend)
+{
+    int *H = (int *)malloc((size_t)(lx + 1) * 2 * sizeof(int));
+    if (!H) return INT_MIN;
+    int *E = H + lx + 1;
+    const int gf = gap_open + gap_extend;
+    for (int j = 0; j <= lx; j++) { H[j] = 0; E[j] = SW_NEG_INF; }
+    int best = 0;
+    for (int iy = 1; iy <= ly; iy++) {
+        int hdiag = 0, hleft = 0, f = SW_NEG_INF;
+        for (int ix = 1; ix <= lx; ix++) {
+            int e = imax(add_inf(H[ix], gf), add_inf(E[ix], gap_extend));
+            f = imax(add_inf(hleft, gf), add_inf(f, gap_extend));
+            int s = hdiag + (sy[iy - 1] == sx[ix - 1] ? match : mismatch);
+            int v = imax(imax(e, f), imax(s, 0));
+            hdiag = H[ix];
+            H[ix] = v; E[ix] = e; hleft = v;
+            if (v > best) best = v;
+        }
+    }
+    free(H);
+    return best;
+}
+
+int oracle_sw_batch_scored(const unsigned char *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
+                           int32_t *scores, int match, int mismatch, int gap_open, int gap_extend)
+{
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int s = oracle_sw_score_scored(bases + off[2 * p], (int)len[2 * p], bases + off[2 * p + 1], (int)len[2 * p + 1],
+                                       match, mismatch, gap_open, gap_extend);
+        if (s == INT_MIN) return -1;
+        scores[p] = s;
+    }
+    return 0;
+}
+
+/*
  * Batch form used by the tests and by bench.py's cpu_baseline leg:
  * seq k lives at bases+off[k], len[k] bytes; pair p = (2p, 2p+1).
  * variant 0 = antidiag port, 1 = rowmajor.

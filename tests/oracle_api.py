@@ -20,6 +20,8 @@ class Oracle:
         self.lib = lib
         lib.oracle_sw_batch.argtypes = [u8p, u64p, u32p, C.c_int64, i32p, C.c_int]
         lib.oracle_sw_batch.restype = C.c_int
+        lib.oracle_sw_batch_scored.argtypes = [u8p, u64p, u32p, C.c_int64, i32p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.oracle_sw_batch_scored.restype = C.c_int
         lib.oracle_sw_file.argtypes = [C.c_char_p, i32p, C.c_long, C.POINTER(C.c_int), C.c_int]
         lib.oracle_sw_file.restype = C.c_long
         lib.oracle_pairhmm_batch.argtypes = [u8p, u8p, u8p, u8p, u8p, u64p, u8p, u64p, u32p, u32p, C.c_int,
@@ -37,6 +39,13 @@ class Oracle:
         bases = b.bases if b.bases.size else np.zeros(1, np.uint8)
         rc = self.lib.oracle_sw_batch(bases, b.off, b.len, b.n_pairs, out, variant)
         assert rc == 0
+        return out
+
+    def sw_batch_scored(self, b, scoring):
+        """parametrised Gotoh; scoring = (match, mismatch, gap_open, gap_extend)."""
+        out = np.empty(b.n_pairs, np.int32)
+        bases = b.bases if b.bases.size else np.zeros(1, np.uint8)
+        assert self.lib.oracle_sw_batch_scored(bases, b.off, b.len, b.n_pairs, out, *scoring) == 0
         return out
 
     def sw_file(self, path, variant=0, cap=1 << 22):

@@ -55,3 +55,11 @@ def test_negative_infinity_is_equivalent_to_a_small_constant(oracle):
     for p in range(b.n_pairs):
         seqs += [b"\x01" * 3 + b.seq(2 * p) + b"\x01" * 5, b"\x02" * 4 + b.seq(2 * p + 1) + b"\x02" * 2]
     assert np.array_equal(oracle.sw_batch(synth.sw_from_seqs(seqs)), oracle.sw_batch(b))
+
+
+def test_parametrised_gotoh_equals_reference_variant_at_reference_scoring(oracle):
+    b = synth.sw_pairs(300, 1, 200, seed=77, related_frac=0.5)
+    assert np.array_equal(oracle.sw_batch_scored(b, (1, -1, -3, -1)), oracle.sw_batch(b, 0))
+    # and it reacts to the parameters as a score should
+    b2 = synth.sw_from_seqs([b"ACGTACGTAC", b"ACGTACGTAC", b"AAAACCCC", b"AAAATCCCC"])
+    assert list(oracle.sw_batch_scored(b2, (2, -3, -5, -2))) == [20, 11]  # AAAA + C/T mismatch + CCC = 14 - 3 beats the gapped 16 - 7

@@ -171,3 +171,31 @@ def test_largest_supported_shapes(ctx, oracle):
     got = ctx.sw_score(b)
     assert np.array_equal(got, oracle.sw_batch(b))
     assert got[0] >= 2550
+
+
+@pytest.mark.parametrize("scoring", [(1, -1, -3, -1), (2, -3, -5, -2), (5, -4, -10, -1), (1, -3, 0, -2), (3, -1, -4, 0),
+                                     (12, -100, -50, -7), (2, 0, -1, -1)])
+def test_runtime_scoring_vs_parametrised_oracle(ctx, oracle, scoring):
+    """8f n3.  Only (1,-1,-3,-1) is the reference's; the rest is pinned against the oracle's own Gotoh."""
+    b = synth.sw_pairs(1500, 1, 400, seed=abs(sum(scoring)) + 50, related_frac=0.6)
+    dev = ctx.sw_batch(b, scoring)
+    dev.launch()
+    got = dev.scores()
+    dev.close()
+    assert np.array_equal(got, oracle.sw_batch_scored(b, scoring))
+    if scoring == (1, -1, -3, -1):
+        assert np.array_equal(got, ctx.sw_score(b))
+
+
+def test_scoring_limits(ctx, oracle):
+    b = synth.sw_pairs(4, 10, 20, seed=1)
+    for bad in [(0, -1, -3, -1), (13, -1, -3, -1), (2, 1, -3, -1), (1, -200, -3, -1), (1, -1, 1, -1), (1, -1, -3, -2000)]:
+        with pytest.raises(agx.AgxError) as e:
+            ctx.sw_batch(b, bad)
+        assert e.value.code == agx.E_LIMIT
+    # the largest scores the int16 lanes must hold: match 12 on identical 2560-mers
+    long = synth.sw_from_seqs([b"ACGT" * 640, b"ACGT" * 640])
+    dev = ctx.sw_batch(long, (12, -1, -3, -1))
+    dev.launch()
+    assert list(dev.scores()) == [12 * 2560] == list(oracle.sw_batch_scored(long, (12, -1, -3, -1)))
+    dev.close()
