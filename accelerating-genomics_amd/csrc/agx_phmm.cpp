@@ -108,11 +108,14 @@ void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count,
 }
 
 // 256-entry quality LUT exactly as partition_read() computes it (antidiagsPairHMM.c:104-107)
-void build_lut(double *d, float *f)
+// mis: the mismatch prior per quality byte -- Qr (reference) or Qr/3 (AGX_PHMM_GATK_PRIOR)
+void build_lut(bool gatk_prior, double *d, float *f, double *mis_d, float *mis_f)
 {
     for (int c = 0; c < 256; ++c) {
         d[c] = pow(10.0, -(c - 33.0) * 0.1);
         f[c] = (float)d[c];
+        mis_d[c] = gatk_prior ? d[c] / 3.0 : d[c];
+        mis_f[c] = gatk_prior ? f[c] / 3.0f : f[c];
     }
 }
 
@@ -122,6 +125,7 @@ struct agx_phmm_batch {
     agx_ctx *ctx = nullptr;
     int precision = AGX_PHMM_F64;
     bool probs = false; // read tracks are probabilities (pairHMM() seam), not Phred characters
+    bool gatk_prior = false;
     int64_t n_pairs = 0;
     DevBuf img, groups, tabs, waves, sums, lut, counter;
     std::vector<ClassLaunch> launches;
@@ -143,6 +147,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     int rc = ctx ? agx_bind(ctx) : AGX_OK;
     if (rc) return rc;
     const int n_cu = ctx ? ctx->n_cu : 256;
+    const bool gatk_prior = (precision & AGX_PHMM_GATK_PRIOR) != 0;
+    precision &= ~AGX_PHMM_GATK_PRIOR;
     if (!d || precision < AGX_PHMM_F64 || precision > AGX_PHMM_F32) {
         agx_set_error("agx_phmm_batch_create: bad descriptor or precision %d", precision);
         return AGX_E_ARG;
@@ -314,7 +320,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 const Plan &p = plan[i];
                 const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
                 const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                if (n > 0 && ntabs_new > 1 && ph_tab_bytes(f64, nsteps + G - 1) * ntabs_new > kTabBudget) break;
+                if (n > 0 && ntabs_new > 1 && ph_tab_bytes(f64, gatk_prior, nsteps + G - 1) * ntabs_new > kTabBudget) break;
                 if (p.read != last_read) {
                     put_read(p.read);
                     tabs.push_back(PhTab{read_dw[p.read], p.R});
@@ -341,8 +347,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             w.n_groups = (uint16_t)n;
             w.n_tabs = (uint16_t)ntabs;
             w.steps = steps;
-            cl.lds = std::max(cl.lds, ph_tab_bytes(f64, steps + G - 1) * ntabs);
-            cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, steps + G - 1) * ntabs);
+            cl.lds = std::max(cl.lds, ph_tab_bytes(f64, gatk_prior, steps + G - 1) * ntabs);
+            cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
             padded += (int64_t)steps * 64 * cl.C;
             waves.push_back(w);
         }
@@ -360,6 +366,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->ctx = ctx;
     b->precision = precision;
     b->probs = probs;
+    b->gatk_prior = gatk_prior;
     b->n_pairs = n_pairs;
     b->launches = launches;
     b->info.n_pairs = n_pairs;
@@ -373,15 +380,15 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         *out = b;
         return AGX_OK;
     }
-    double lut_d[256];
-    float lut_f[256];
-    build_lut(lut_d, lut_f);
+    double lut_d[256], mis_d[256];
+    float lut_f[256], mis_f[256];
+    build_lut(gatk_prior, lut_d, lut_f, mis_d, mis_f);
     rc = b->img.alloc(img.size() * 4);
     if (!rc) rc = b->groups.alloc(groups.size() * sizeof(PhGroup));
     if (!rc) rc = b->tabs.alloc(tabs.size() * sizeof(PhTab));
     if (!rc) rc = b->waves.alloc(waves.size() * sizeof(PhWave));
     if (!rc) rc = b->sums.alloc((size_t)n_pairs * sizeof(double));
-    if (!rc) rc = b->lut.alloc(sizeof lut_d + sizeof lut_f);
+    if (!rc) rc = b->lut.alloc(2 * (sizeof lut_d + sizeof lut_f)); // [lut_d][lut_f][mis_d][mis_f]
     if (!rc) rc = b->counter.alloc(sizeof(unsigned long long));
     if (rc) {
         agx_phmm_batch_destroy(b);
@@ -397,6 +404,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     up(b->waves, waves.data(), waves.size() * sizeof(PhWave));
     up(b->lut, lut_d, sizeof lut_d);
     if (e == hipSuccess) e = hipMemcpy((char *)b->lut.p + sizeof lut_d, lut_f, sizeof lut_f, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy((char *)b->lut.p + sizeof lut_d + sizeof lut_f, mis_d, sizeof mis_d, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy((char *)b->lut.p + 2 * sizeof lut_d + sizeof lut_f, mis_f, sizeof mis_f, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(b->sums.p, 0, b->sums.bytes); // degenerate pairs keep sum 0
     if (e == hipSuccess) e = hipMemset(b->counter.p, 0, b->counter.bytes);
     if (e != hipSuccess) {
@@ -449,6 +460,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     hipStream_t s = b->ctx->stream;
     const void *lut_d = b->lut.p;
     const void *lut_f = (const char *)b->lut.p + 256 * sizeof(double);
+    const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
+    const void *mis_f = (const char *)b->lut.p + 256 * (2 * sizeof(double) + sizeof(float));
     const int passes = b->precision == AGX_PHMM_F32 ? 2 : 1;
     if (passes == 2) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
     // the counter reset above is ordered before the fork; each class's fill and (F32) its double
@@ -468,7 +481,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
             const size_t lds = pass == 1 ? cl.lds_rescue : cl.lds; // same records, wider table rows
             const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->groups.p,
                                                 (const PhTab *)b->tabs.p, (const PhWave *)b->waves.p + cl.first_wave,
-                                                cl.n_waves, f64 ? lut_d : lut_f, (double *)b->sums.p,
+                                                cl.n_waves, f64 ? lut_d : lut_f, b->gatk_prior ? (f64 ? mis_d : mis_f) : nullptr,
+                                                (double *)b->sums.p,
                                                 (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, st);
             if (r) {
                 agx_set_error("phmm_fill<C=%d, mode %d> launch failed: %s", cl.C, mode, hipGetErrorString(hipGetLastError()));

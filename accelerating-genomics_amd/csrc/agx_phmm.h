@@ -48,13 +48,18 @@ static const double kPhClassCost[3][19] = {
     {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
 };
 
-// bytes of LDS one table row takes (four probabilities + the read base)
-__host__ __device__ static inline size_t ph_row_bytes(bool f64) { return (f64 ? 8u : 4u) * 4u + 1u; }
-__host__ __device__ static inline size_t ph_tab_bytes(bool f64, uint32_t rows) { return (ph_row_bytes(f64) * rows + 15u) & ~(size_t)15u; }
+// bytes of LDS one table row takes: Qr, Qi, Qd, Qg (+ a separate mismatch prior when it is not
+// Qr itself, AGX_PHMM_GATK_PRIOR) + the read base
+__host__ __device__ static inline size_t ph_row_bytes(bool f64, bool mis_col) { return (f64 ? 8u : 4u) * (mis_col ? 5u : 4u) + 1u; }
+__host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, uint32_t rows)
+{
+    return (ph_row_bytes(f64, mis_col) * rows + 15u) & ~(size_t)15u;
+}
 
 // mode: 0 = f64 reference order, 1 = f64 with FMA contraction, 2 = f32, 3 = f64 rescue pass
 // over an f32 result (only groups whose sums[out] < rescue_below are recomputed), 4 = f64
 // reference order with probability tracks instead of Phred characters (pairHMM() seam).
 int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
-                          const PhWave *waves, uint32_t n_waves, const void *lut, double *sums, double rescue_below,
+                          const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
+                          double rescue_below,
                           unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s);

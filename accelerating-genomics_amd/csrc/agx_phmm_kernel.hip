@@ -67,7 +67,8 @@ template <bool FMA> __device__ __forceinline__ float mad(float a, float b, float
 template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
 __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                                 const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
-                                                uint32_t n_waves, const T *__restrict__ lut, double *__restrict__ sums,
+                                                uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
+                                                double *__restrict__ sums,
                                                 double rescue_below, unsigned long long *__restrict__ n_rescued)
 {
     constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
@@ -100,16 +101,18 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
 
     // ---- read tables -> LDS
     const uint32_t rows = w.steps + (uint32_t)G - 1u;
-    const size_t tab_bytes = ph_tab_bytes(sizeof(T) == 8, rows);
+    const bool mis_col = lut_mis != nullptr; // wave-uniform: a fifth table column holds the mismatch prior
+    const uint32_t ncol = mis_col ? 5u : 4u;
+    const size_t tab_bytes = ph_tab_bytes(sizeof(T) == 8, mis_col, rows);
     for (uint32_t k = 0; k < w.n_tabs; ++k) {
         const PhTab tb = tabs[w.first_tab + k];
         T *tq = reinterpret_cast<T *>(lds + k * tab_bytes);
-        unsigned char *tc = reinterpret_cast<unsigned char *>(tq + 4 * rows);
+        unsigned char *tc = reinterpret_cast<unsigned char *>(tq + ncol * rows);
         const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
         const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
         for (uint32_t r = lane; r < rows; r += 64) {
             const int i = (int)r - (G - 1);
-            T vr = 0, vi = 0, vd = 0, vg = 1; // neutral row
+            T vr = 0, vi = 0, vd = 0, vg = 1, vm = 0; // neutral row
             unsigned char c = 0;
             if (i >= 0 && i < (int)tb.R) {
                 if constexpr (PROBS) { // pairHMM() seam: tracks are probabilities, bases follow them
@@ -122,6 +125,7 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
                 } else {
                     c = rp[i];
                     vr = lut[rp[trk + i]];
+                    if (mis_col) vm = lut_mis[rp[trk + i]]; // Qr/3 (AGX_PHMM_GATK_PRIOR)
                     vi = lut[rp[2 * trk + i]];
                     vd = lut[rp[3 * trk + i]];
                     vg = lut[rp[4 * trk + i]];
@@ -131,14 +135,16 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
             tq[rows + r] = vi;
             tq[2 * rows + r] = vd;
             tq[3 * rows + r] = vg;
+            if (mis_col) tq[4 * rows + r] = vm;
             tc[r] = c;
         }
     }
     __syncthreads();
 
+    const uint32_t mis_off = mis_col ? 4u * rows : 0u; // branch-free: without the column, re-read Qr
     const uint32_t tabi = g.R_tab >> 16;
     const T *tq = reinterpret_cast<const T *>(lds + tabi * tab_bytes) + (G - 1 - gl);
-    const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + 4 * rows * sizeof(T)) + (G - 1 - gl);
+    const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + ncol * rows * sizeof(T)) + (G - 1 - gl);
 
     // lane gl owns haplotype bytes [gl*C, gl*C + C): fetch the covering dwords and byte-align them
     // (C need not be a multiple of 4; every haplotype is followed by zero slack)
@@ -175,9 +181,10 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
         constexpr bool HAPN = decltype(hapn_tag)::value;
         for (int t = 0; t < steps; ++t) {
             const T q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
+            const T q_m = tq[mis_off + t]; // mismatch prior: the reference's is Qr itself (mis_off = 0)
             const uint32_t rc = tc[t];
             const T pm = 1 - q_r;                        // p(): match or N (:111-113)
-            const T pq = rc == (uint32_t)'N' ? pm : q_r; //      mismatch
+            const T pq = rc == (uint32_t)'N' ? pm : q_m; //      mismatch
             const T mm = 1 - (q_i + q_d);                // mm() (:115-117)
             const T gm = 1 - q_g;
 
@@ -241,35 +248,36 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
 
 template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
-           const void *lut, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds, hipStream_t s)
+           const void *lut, const void *lut_mis, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds,
+           hipStream_t s)
 {
     auto k = phmm_fill<T, C, FMA, RESCUE, PROBS>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
     }
-    hipLaunchKernelGGL(k, dim3(n_waves), dim3(64), lds, s, img, groups, tabs, waves, n_waves, (const T *)lut, sums,
+    hipLaunchKernelGGL(k, dim3(n_waves), dim3(64), lds, s, img, groups, tabs, waves, n_waves, (const T *)lut, (const T *)lut_mis, sums,
                        rescue_below, n_rescued);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <int C>
 int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
-                uint32_t n_waves, const void *lut, double *sums, double rescue_below, unsigned long long *n_rescued,
-                size_t lds, hipStream_t s)
+                uint32_t n_waves, const void *lut, const void *lut_mis, double *sums, double rescue_below,
+                unsigned long long *n_rescued, size_t lds, hipStream_t s)
 {
     if constexpr (C > 32) { // wider than 32 columns only exists in float (VGPR budget)
-        if (mode == 2) return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+        if (mode == 2) return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
         // the double rescue pass of a float batch reuses the float batch's records (rare, may spill)
-        if (mode == 3) return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+        if (mode == 3) return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
         return -2;
     } else
     switch (mode) {
-    case 0: return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
-    case 1: return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
-    case 2: return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
-    case 3: return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
-    case 4: return launch<double, C, false, false, true>(img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds, s);
+    case 0: return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 1: return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 2: return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 3: return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 4: return launch<double, C, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
     default: return -2;
     }
 }
@@ -277,12 +285,12 @@ int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTa
 } // namespace
 
 int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
-                          const PhWave *waves, uint32_t n_waves, const void *lut, double *sums, double rescue_below,
-                          unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s)
+                          const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
+                          double rescue_below, unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s)
 {
     if (n_waves == 0) return 0;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, sums, rescue_below, n_rescued, lds_bytes, s);
+    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds_bytes, s);
     switch (cols_per_lane) {
         AGX_PH_FOR_EACH_CLASS(AGX_PH_CASE)
     default: return -2;

@@ -162,6 +162,10 @@ typedef struct agx_phmm_desc {
                                pairs whose float sum falls below AGX_PHMM_F32_RESCUE are
                                recomputed with AGX_PHMM_F64 on the device */
 #define AGX_PHMM_F32_RESCUE 1e-28f
+/* OR-able into `precision` (8f n4, default off): mismatch prior Qr/3 as GATK's PairHMM uses, instead
+ * of the reference's Qr (antidiagsPairHMM.c:111-113).  Not a behaviour of the
+ * reference: checked against the oracle's own restatement only. */
+#define AGX_PHMM_GATK_PRIOR 0x100
 
 typedef struct agx_phmm_batch agx_phmm_batch;
 

@@ -77,6 +77,41 @@ double oracle_pairhmm_sum_f64(const unsigned char *R, int rl, const unsigned cha
     return l;
 }
 
+/*
+ * Same recurrence with GATK's mismatch prior Qr/3.  NOT a behaviour of the
+ * reference ("parity unpinned"): it only pins the product's AGX_PHMM_GATK_PRIOR option against
+ * this restatement.
+ */
+double oracle_pairhmm_sum_f64_gatk(const unsigned char *R, int rl, const unsigned char *H, int hl,
+                                   const double *Qr, const double *Qi, const double *Qd, const double *Qg)
+{
+    size_t w = (size_t)hl + 1;
+    double *buf = (double *)calloc(6 * w, sizeof(double));
+    if (!buf) return NAN;
+    double *Mp = buf, *Xp = buf + w, *Yp = buf + 2 * w, *Mc = buf + 3 * w, *Xc = buf + 4 * w, *Yc = buf + 5 * w;
+    double init = DBL_MAX / 16 / (double)hl;
+    for (int j = 0; j <= hl; j++) Yp[j] = init;
+    for (int i = 1; i <= rl; i++) {
+        Mc[0] = Xc[0] = Yc[0] = 0;
+        double qr = Qr[i - 1], qi = Qi[i - 1], qd = Qd[i - 1], qg = Qg[i - 1];
+        for (int j = 1; j <= hl; j++) {
+            unsigned char r = R[i - 1], h = H[j - 1];
+            double prior = (r == h || r == 'N' || h == 'N') ? 1 - qr : qr / 3.0;
+            Mc[j] = prior * ((1 - (qi + qd)) * Mp[j - 1] + (1 - qg) * (Xp[j - 1] + Yp[j - 1]));
+            Xc[j] = Mp[j] * qi + Xp[j] * qg;
+            Yc[j] = Mc[j - 1] * qd + Yc[j - 1] * qg;
+        }
+        double *t;
+        t = Mp; Mp = Mc; Mc = t;
+        t = Xp; Xp = Xc; Xc = t;
+        t = Yp; Yp = Yc; Yc = t;
+    }
+    double l = 0;
+    for (int j = 1; j <= hl; j++) l += (Mp[j] + Xp[j]);
+    free(buf);
+    return l;
+}
+
 /* log10 likelihood exactly as likelihood() returns it (pairHMMmatrix.c:65) */
 double oracle_pairhmm_log10_f64(const unsigned char *R, int rl, const unsigned char *H, int hl,
                                 const double *Qr, const double *Qi, const double *Qd, const double *Qg)
@@ -170,7 +205,7 @@ float oracle_pairhmm_sum_f32(const unsigned char *R, int rl, const unsigned char
  * haps h: hb+hoff[h]; regions g: reads [rreg[g], rreg[g+1]) x haps
  * [hreg[g], hreg[g+1]); output read-major, hap-minor inside a region, regions
  * in order (antidiagsPairHMM.c:411,440).  variant: 0 row-major f64,
- * 1 antidiag f64, 2 row-major f32.  out_sum receives raw sums (may be NULL),
+ * 1 antidiag f64, 2 row-major f32, 3 row-major f64 with the GATK mismatch prior.  out_sum receives raw sums (may be NULL),
  * out_log10 the printed quantity.
  */
 int oracle_pairhmm_batch(const unsigned char *rb, const unsigned char *qb, const unsigned char *qi_,
@@ -199,6 +234,7 @@ int oracle_pairhmm_batch(const unsigned char *rb, const unsigned char *qb, const
                 double c = log10(DBL_MAX / 16);
                 if (variant == 0) s = oracle_pairhmm_sum_f64(rb + roff[r], rl, hb + hoff[h], hl, Qr, Qi, Qd, Qg);
                 else if (variant == 1) s = oracle_pairhmm_sum_f64_antidiag(rb + roff[r], rl, hb + hoff[h], hl, Qr, Qi, Qd, Qg);
+                else if (variant == 3) s = oracle_pairhmm_sum_f64_gatk(rb + roff[r], rl, hb + hoff[h], hl, Qr, Qi, Qd, Qg);
                 else { s = (double)oracle_pairhmm_sum_f32(rb + roff[r], rl, hb + hoff[h], hl, Qr, Qi, Qd, Qg); c = log10((double)(FLT_MAX / 16)); }
                 if (out_sum) out_sum[k] = s;
                 if (out_log10) out_log10[k] = log10(s) - c;

@@ -224,3 +224,18 @@ def test_largest_supported_shapes(ctx, oracle):
     got32 = ctx.phmm_forward(b, agx.PHMM_F32)
     assert relerr(got32, l_ref) <= 1e-6
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), l_ref) <= 1e-12
+
+
+def test_gatk_prior_option(ctx, oracle, golden_dir):
+    """8f n4, default off: mismatch prior Qr/3.  Not the reference's behaviour -- checked against the
+    oracle's own restatement (variant 3); the reference-mode result must differ."""
+    b, _, _ = agx.read_phmm_text(os.path.join(golden_dir, "phmm_10s.in"))
+    s_ref, l_ref = oracle.phmm_batch(b, 3)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR)
+    dev.launch()
+    l, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, s_ref)
+    assert not np.array_equal(l, g17(golden_dir, "phmm_10s"))
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F32 | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-6
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-12
