@@ -31,9 +31,9 @@ bool use_packed_kernel()
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
 // cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
 // by the measured per-cell cost of the class.
-inline double tiling_cost(int ly, int ci, int G)
+inline double tiling_cost(bool packed, int ly, int ci, int G)
 {
-    const double wgt = use_packed_kernel() ? kSwPkClassCost[ci] : kSwClassCost[ci];
+    const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
     return (double)(ly + G - 1) * kSwClasses[ci] * (64.0 / (double)(64 / G)) * wgt;
 }
 
@@ -58,7 +58,7 @@ int force_cols_per_lane()
     return v;
 }
 
-Tiling choose_tiling(int lx, int ly)
+Tiling choose_tiling(bool packed, int lx, int ly)
 {
     Tiling best{-1, 0};
     double best_cost = 0;
@@ -68,7 +68,8 @@ Tiling choose_tiling(int lx, int ly)
         if (G > 64) continue;
         if (C > max_cols_per_lane() && best.cls >= 0) continue;
         if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
-        const double c = tiling_cost(ly, ci, G);
+        if ((packed ? kSwPkClassCost[ci] : kSwClassCost[ci]) == 0) continue; // class not built for this kernel
+        const double c = tiling_cost(packed, ly, ci, G);
         if (best.cls < 0 || c < best_cost || (c == best_cost && C > kSwClasses[best.cls])) {
             best = Tiling{ci, G};
             best_cost = c;
@@ -80,11 +81,11 @@ Tiling choose_tiling(int lx, int ly)
 // Uniform batches (most pairs share one shape, e.g. fixed-length reads): every wave of that shape
 // costs the same, so the launch lasts ceil(waves / SIMDs) wave-times -- the tiling is chosen for the
 // whole shape with that quantisation instead of pair by pair.
-Tiling choose_tiling_uniform(int lx, int ly, int64_t count, int n_simd)
+Tiling choose_tiling_uniform(bool packed, int lx, int ly, int64_t count, int n_simd)
 {
     Tiling best{-1, 0};
     double best_cost = 0;
-    const int slots = use_packed_kernel() ? 2 : 1;
+    const int slots = packed ? 2 : 1;
     for (int ci = 0; ci < kSwNumClasses; ++ci) {
         const int C = kSwClasses[ci];
         const int G = (lx + C - 1) / C;
@@ -94,7 +95,8 @@ Tiling choose_tiling_uniform(int lx, int ly, int64_t count, int n_simd)
         const int64_t per_wave = (int64_t)(64 / G) * slots;
         const int64_t waves = (count + per_wave - 1) / per_wave;
         const int64_t rounds = (waves + n_simd - 1) / n_simd;
-        const double wgt = use_packed_kernel() ? kSwPkClassCost[ci] : kSwClassCost[ci];
+        const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
+        if (wgt == 0) continue;
         const double c = (double)rounds * (ly + G - 1) * C * wgt;
         if (best.cls < 0 || c < best_cost) {
             best = Tiling{ci, G};
@@ -193,7 +195,16 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     prm.hd2 = twice(prm.hd);
     prm.delta2 = twice(prm.delta);
     prm.zero_score2 = twice(prm.gf);
-    const uint32_t max_short = std::min<uint32_t>(AGX_SW_MAX_SHORT_LEN, 32000u / (uint32_t)sc.match);
+    // the packed int16 kernel covers shorter sides up to 64 x 40 columns; one longer pair moves the
+    // whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160)
+    bool packed = use_packed_kernel();
+    if (packed)
+        for (int64_t p = 0; p < n_pairs; ++p)
+            if (std::min(len[2 * p], len[2 * p + 1]) > (uint32_t)kSwPackedMaxShort) {
+                packed = false;
+                break;
+            }
+    const uint32_t max_short = AGX_SW_MAX_SHORT_LEN;
 
     const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -231,7 +242,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
             if (lx > max_short || ly > 0xffffu) rc = AGX_E_LIMIT;
             else if (memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb)) rc = AGX_E_SYMBOL;
             else {
-                tl = choose_tiling((int)lx, (int)ly);
+                tl = choose_tiling(packed, (int)lx, (int)ly);
                 if (tl.cls < 0) rc = AGX_E_LIMIT;
             }
             if (rc != AGX_OK) {
@@ -280,7 +291,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
             for (const PairPlan &pp : all)
                 if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) ++count;
         if (count * 2 >= n_pairs) {
-            const Tiling tl = choose_tiling_uniform((int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * n_cu);
+            const Tiling tl = choose_tiling_uniform(packed, (int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * n_cu);
             if (tl.cls >= 0)
                 for (PairPlan &pp : all)
                     if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) {
@@ -322,7 +333,6 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
 
     // ---- form waves and lay out the image (offsets only), then copy the bytes with threads.
     // Packed kernel: a group carries up to two pairs (slots); the int32 kernel one.
-    const bool packed = use_packed_kernel();
     const int slots = packed ? 2 : 1;
     struct Slot {
         int32_t plan[2]; // indices into plan[], -1 = empty second slot
@@ -333,7 +343,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
     // word 0.. of the image: a zero block any empty slot points at (x of up to 64*40 bytes)
-    size_t img_dw = packed ? (size_t)AGX_SW_MAX_SHORT_LEN / 4 + 1 : 0;
+    size_t img_dw = packed ? (size_t)kSwPackedMaxShort / 4 + 1 : 0;
     std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
     size_t i = 0;
     while (i < plan.size()) {
@@ -416,7 +426,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
         agx_set_error("agx_sw_batch_create: out of host memory for the packed image");
         return AGX_E_NOMEM;
     }
-    if (packed) memset(img.p, 0, (size_t)AGX_SW_MAX_SHORT_LEN + 4);
+    if (packed) memset(img.p, 0, (size_t)kSwPackedMaxShort + 4);
     agx_parallel_for((int64_t)plan.size(), 2048, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             const PairPlan &pp = plan[(size_t)k];
@@ -499,9 +509,9 @@ int agx_sw_batch_launch(agx_sw_batch *b)
                           ? agx_sw_pk_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                    (int32_t *)b->scores.p, st)
-                          : agx_sw_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
-                                                (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                                (int32_t *)b->scores.p, st);
+                          : (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(
+                                cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
+                                (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves, (int32_t *)b->scores.p, st);
         if (r) {
             agx_set_error("sw_fill<%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;

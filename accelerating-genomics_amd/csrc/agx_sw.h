@@ -51,16 +51,21 @@ struct SwWave {
 // byte-aligned on load), every even width so that common lengths tile with little padding.
 #define AGX_SW_FOR_EACH_CLASS(X) \
     X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
-static const int kSwClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
+// wide classes: int32 kernel only, for shorter sides beyond 64 x 40 columns (agx_sw_wide_kernel.hip)
+#define AGX_SW_FOR_EACH_WIDE_CLASS(X) X(80) X(120) X(160)
+static const int kSwClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 80, 120, 160};
+static const int kSwPackedMaxShort = 64 * 40; // the packed kernel has no wide classes
 static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
 // Measured lane time per padded cell of each class, relative to the widest one (MI355X,
 // tools/calibrate_classes.py, profiles/r01_calibration*.log): narrow classes amortise the
 // per-step work (DPP shifts, row symbol, loop control) over fewer cells.
-static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 1.036, 1.025, 1.029, 1.022, 1.018, 1.011, 1.011, 1.007, 1.004, 1.004, 1.004, 1.004, 1.000};
+static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 1.036, 1.025, 1.029, 1.022, 1.018, 1.011, 1.011, 1.007, 1.004, 1.004, 1.004, 1.004, 1.000, 1.6, 2.2, 4.0};
 // same for the packed int16 kernel
-static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000};
+static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
 
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
+int agx_sw_wide_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
+                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);

@@ -42,8 +42,10 @@ extern "C" {
 /* Smith-Waterman: the shorter sequence of a pair is laid across lanes, at most
  * 64 lanes x AGX_SW_MAX_COLS_PER_LANE columns; the longer one streams.  (The
  * reference CLI cannot produce lines of 1000 bytes or more,
- * antidiagonalSmithWaterman.c:44; hipvers.cpp:40 allows 10000.) */
-#define AGX_SW_MAX_COLS_PER_LANE 40
+ * antidiagonalSmithWaterman.c:44; hipvers.cpp:40 allows 10000.)  Batches whose
+ * shorter sides all fit 64 x 40 = 2560 columns run the packed kernel; a batch
+ * with a longer one runs the int32 kernel with its wide classes. */
+#define AGX_SW_MAX_COLS_PER_LANE 160
 #define AGX_SW_MAX_SHORT_LEN (64 * AGX_SW_MAX_COLS_PER_LANE)
 /* PairHMM: haplotype across lanes (64 x AGX_PHMM_MAX_COLS_PER_LANE), read streams. */
 #define AGX_PHMM_MAX_COLS_PER_LANE 32

@@ -42,9 +42,10 @@ def test_validation_errors_need_no_device():
         plan_sw(synth.sw_from_seqs([b"AC\x00GT", b"ACGT"]))
     assert e.value.code == agx.E_SYMBOL
     with pytest.raises(agx.AgxError) as e:
-        plan_sw(synth.sw_from_seqs([b"A" * 2561, b"C" * 2561]))
+        plan_sw(synth.sw_from_seqs([b"A" * 10241, b"C" * 10241]))
     assert e.value.code == agx.E_LIMIT
-    plan_sw(synth.sw_from_seqs([b"A" * 2560, b"C" * 60000]))  # the limits themselves are fine
+    plan_sw(synth.sw_from_seqs([b"A" * 10240, b"C" * 60000]))  # the limits themselves are fine
+    assert plan_sw(synth.sw_from_seqs([b"A" * 2561, b"C" * 2561]))["waves"] == 1  # int32 kernel, wide class
 
 
 def test_planned_batch_cannot_run():

@@ -77,7 +77,7 @@ def test_reserved_symbol_and_limits_fail_loudly(ctx):
         ctx.sw_score(synth.sw_from_seqs([b"AC\x00GT", b"ACGT"]))
     assert e.value.code == agx.E_SYMBOL
     with pytest.raises(agx.AgxError) as e:
-        ctx.sw_score(synth.sw_from_seqs([b"A" * 3000, b"C" * 3000]))
+        ctx.sw_score(synth.sw_from_seqs([b"A" * 10241, b"C" * 10241]))
     assert e.value.code == agx.E_LIMIT
 
 
@@ -199,3 +199,17 @@ def test_scoring_limits(ctx, oracle):
     dev.launch()
     assert list(dev.scores()) == [12 * 2560] == list(oracle.sw_batch_scored(long, (12, -1, -3, -1)))
     dev.close()
+
+
+def test_wide_classes_beyond_the_packed_kernel(ctx, oracle):
+    """Shorter sides of 2561..10240 symbols (hipvers.cpp:40 reads lines up to 9999 bytes): one such
+    pair moves the batch to the int32 kernel with its 80/120/160-column classes."""
+    rng = np.random.default_rng(41)
+    seqs = []
+    for lx, ly in ((2561, 2561), (4000, 4500), (7680, 7680), (9999, 9999), (10240, 12000), (100, 120)):
+        a = bytes(rng.choice(list(b"ACGT"), size=lx).tolist())
+        y = bytearray(rng.choice(list(b"ACGT"), size=ly).tolist())
+        y[ly - lx : ly - lx + lx // 2] = a[: lx // 2]  # half of a embedded
+        seqs += [a, bytes(y)]
+    b = synth.sw_from_seqs(seqs)
+    assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b))
