@@ -30,9 +30,6 @@
 
 #include <type_traits>
 
-#ifndef AGX_DPP_MOV
-#define AGX_DPP_MOV 0
-#endif
 
 #pragma clang fp contract(off)
 
@@ -41,11 +38,7 @@ namespace {
 // DPP wave_shr:1: lane i receives lane i-1's v; lane 0 (always a group's first lane) overrides it.
 __device__ __forceinline__ int shr1i(int v)
 {
-#if AGX_DPP_MOV
-    return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, false);
-#else
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false);
-#endif
 }
 __device__ __forceinline__ float shr1(float v) { return __int_as_float(shr1i(__float_as_int(v))); }
 __device__ __forceinline__ double shr1(double v)

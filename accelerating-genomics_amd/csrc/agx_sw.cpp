@@ -194,7 +194,6 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     prm.gf2 = twice(prm.gf);
     prm.hd2 = twice(prm.hd);
     prm.delta2 = twice(prm.delta);
-    prm.zero_score2 = twice(prm.gf);
     // the packed int16 kernel covers shorter sides up to 64 x 40 columns; one longer pair moves the
     // whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160)
     bool packed = use_packed_kernel();

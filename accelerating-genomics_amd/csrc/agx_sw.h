@@ -24,7 +24,7 @@ struct SwParams {
     int32_t delta;   // match - mismatch (> 0)
     int32_t shift;   // packed kernel: symbols are compared as byte << shift, 2^shift >= delta
     // the same, replicated into both 16-bit halves for the packed kernel
-    uint32_t ge2, gf2, hd2, delta2, zero_score2;
+    uint32_t ge2, gf2, hd2, delta2;
 };
 
 // Packed kernel: one group of G lanes carries two pairs (index 0 = low 16 bits, 1 = high 16 bits

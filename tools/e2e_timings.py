@@ -1,5 +1,5 @@
 import sys, time, numpy as np, os, subprocess, tempfile
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
 ctx = agx.Context(0)
 b = synth.sw_pairs(65536,150,150,seed=2, related_frac=0.25)
