@@ -5,6 +5,9 @@
  * (`#batch: k` at the top of every loop turn, including the one that meets EOF, and every
  * value), same failure behaviour on a truncated batch.  pairHMM() (:120-267) runs on the GPU
  * through libagx (include/agx.h); there is no CPU path.
+ * Built a second time as `pairHMMmatrix` (-DAGX_PHMM_MATRIX_STDOUT): the reference's row-major
+ * program pairHMM/pairHMMmatrix.c has the same command line and output file but prints only the
+ * `#batch:` lines on stdout (:171 vs its fprintf at :258).
  *   AGX_PHMM_PRECISION = f64 (default; raw sums bit-identical to the reference) | f64fma | f32
  *   AGX_NUM_DEVICES    = n GPUs to shard whole batches over (default 1, 0 = all)
  */
@@ -54,7 +57,9 @@ int main(int argc, const char *argv[])
         printf("#batch: %u\n", g + 1); /* :372 */
         int64_t n = (int64_t)(d->region_read[g + 1] - d->region_read[g]) * (d->region_hap[g + 1] - d->region_hap[g]);
         for (int64_t i = 0; i < n; i++, k++) {
+#ifndef AGX_PHMM_MATRIX_STDOUT
             printf("%f\n", lh[k]);       /* :459 */
+#endif
             fprintf(out, "%f\n", lh[k]); /* :461 */
         }
     }
