@@ -1,0 +1,41 @@
+"""AddressSanitizer + UBSan over the host side of libagx (text readers, planners, packers) on the CPU
+build: the device objects are linked unchanged, no device is touched (plan-only batches)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "accelerating-genomics_amd")
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not present")
+def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
+    import accelerating_genomics_amd.api as agx
+
+    if not os.path.exists(os.path.join(PKG, "build", "agx_sw_pk_kernel.o")):
+        agx.build()
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"]
+    objs = []
+    for src in ("agx_runtime.cpp", "agx_sw.cpp", "agx_phmm.cpp"):
+        o = str(tmp_path / (src + ".o"))
+        subprocess.run([CLANG + "++", "-std=c++17", "-x", "c++", *san, *inc, "-c", os.path.join(PKG, "csrc", src), "-o", o], check=True)
+        objs.append(o)
+    for src, extra in ((os.path.join(PKG, "csrc", "agx_text.c"), ["-D_POSIX_C_SOURCE=200809L"]),
+                       (os.path.join(ROOT, "tests", "host", "sanitize_driver.c"), [])):
+        o = str(tmp_path / (os.path.basename(src) + ".o"))
+        subprocess.run([CLANG, "-std=c99", *san, *inc, *extra, "-c", src, "-o", o], check=True)
+        objs.append(o)
+    dev = [os.path.join(PKG, "build", n) for n in ("agx_sw_kernel.o", "agx_sw_wide_kernel.o", "agx_sw_pk_kernel.o", "agx_phmm_kernel.o")]
+    exe = str(tmp_path / "sanitize_driver")
+    subprocess.run([CLANG + "++", *san, *objs, *dev, "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               AGX_HOST_THREADS="4")
+    r = subprocess.run([exe, golden_dir], capture_output=True, env=env, timeout=600)
+    tail = (r.stdout + r.stderr).decode(errors="replace")[-3000:]
+    assert r.returncode == 0 and b"SANITIZE_DRIVER_OK" in r.stdout, tail
+    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, tail
