@@ -25,8 +25,11 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Usage: %s <file_path>\n", argv[0]); /* :190-193 */
         return 1;
     }
+    const int trace = getenv("AGX_TRACE_CLI") != NULL;
+    double tr0 = seconds();
     agx_sw_text *t = NULL;
     int rc = agx_sw_text_read(argv[1], 0, &t);
+    if (trace) fprintf(stderr, "[cli] read+parse %.3f s\n", seconds() - tr0);
     if (rc != AGX_OK) {
         if (strcmp(agx_last_error(), "file is empty") == 0) { /* :205-208 */
             printf("file is empty");
@@ -49,7 +52,10 @@ int main(int argc, char *argv[])
         fprintf(stderr, "antidiagonalSmithWaterman: %s\n", agx_last_error());
         return EXIT_FAILURE;
     }
+    if (trace) fprintf(stderr, "[cli] score %.3f s\n", seconds() - t0);
+    tr0 = seconds();
     for (int64_t p = 0; p < t->n_pairs; p++) printf("Score: %d\n", scores[p]); /* :348 */
+    if (trace) fprintf(stderr, "[cli] print %.3f s\n", seconds() - tr0);
     if (t->dangling) printf("%s", t->dangling);                                /* :225 */
     printf("elapsed %f\n", seconds() - t0);                                    /* :351-352 */
     free(scores);

@@ -75,6 +75,29 @@ def cpu_baseline_sw(n_pairs):
             "sample": "%d of the 65536 config-2 pairs, antidiagonalSmithWaterman.c incl. its text parsing, %.1f s" % (n_pairs, dt)}
 
 
+def cpu_baseline_sw_multicore(n_procs, pairs_each):
+    """BASELINE.md section 3 also asks for an embarrassingly-parallel run: n_procs copies of the reference
+    program, one shard each, all started together (the box's CPU share for one GPU is 16 cores)."""
+    import accelerating_genomics_amd.synth as synth
+
+    ref = os.path.join(ROOT, "oracle", "_ref", "sw_ref")
+    if not os.access(ref, os.X_OK):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for k in range(n_procs):
+            path = os.path.join(d, "sw%d.in" % k)
+            synth.write_sw_file(path, synth.sw_pairs(pairs_each, SW_LEN, SW_LEN, seed=100 + k, related_frac=0.25))
+            paths.append(path)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([ref, p], stdout=subprocess.DEVNULL) for p in paths]
+        for pr in procs:
+            pr.wait()
+        dt = time.perf_counter() - t0
+    return {"value": n_procs * pairs_each * SW_LEN * SW_LEN / dt / 1e9, "unit": "GCUPS", "cores": n_procs, "kind": "reference",
+            "sample": "%d concurrent copies of antidiagonalSmithWaterman.c, %d pairs each, %.1f s" % (n_procs, pairs_each, dt)}
+
+
 def cpu_baseline_phmm(n_regions):
     import accelerating_genomics_amd.synth as synth
 
@@ -226,6 +249,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
         out["pairhmm"]["cpu_baseline"] = cpu_baseline_phmm(max(1, args.cpu_sample_pairs // (PH_READS * PH_HAPS)))
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        multi_cpu = cpu_baseline_sw_multicore(min(16, os.cpu_count() or 1), 8192)
+        if multi_cpu:
+            out["cpu_baseline_multicore"] = multi_cpu
     print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
