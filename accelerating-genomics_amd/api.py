@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, "libagx.so"))  # override: kernel experiments only
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_SYMBOL, E_LIMIT, E_IO = 0, -1, -2, -3, -4, -5, -6, -7
-PHMM_F64, PHMM_F64_FMA, PHMM_F32 = 0, 1, 2
+PHMM_F64, PHMM_F64_FMA, PHMM_F32, PHMM_F32_FMA = 0, 1, 2, 3
 PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
 
 # every symbol include/agx.h declares (tests check the library exports all of them)

@@ -127,8 +127,13 @@ struct agx_phmm_batch {
     bool probs = false; // read tracks are probabilities (pairHMM() seam), not Phred characters
     bool gatk_prior = false;
     int64_t n_pairs = 0;
-    DevBuf img, groups, tabs, waves, sums, lut, counter;
-    std::vector<ClassLaunch> launches;
+    bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
+    bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
+    DevBuf img, sums, lut, counter;
+    struct DevPlan {
+        DevBuf groups, tabs, waves;
+        std::vector<ClassLaunch> launches;
+    } main, rescue;
     agx_phmm_info info{};
 };
 
@@ -149,7 +154,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     const int n_cu = ctx ? ctx->n_cu : 256;
     const bool gatk_prior = (precision & AGX_PHMM_GATK_PRIOR) != 0;
     precision &= ~AGX_PHMM_GATK_PRIOR;
-    if (!d || precision < AGX_PHMM_F64 || precision > AGX_PHMM_F32) {
+    if (!d || precision < AGX_PHMM_F64 || precision > AGX_PHMM_F32_FMA) {
         agx_set_error("agx_phmm_batch_create: bad descriptor or precision %d", precision);
         return AGX_E_ARG;
     }
@@ -157,7 +162,17 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         agx_set_error("agx_phmm_batch_create: NULL offset table");
         return AGX_E_ARG;
     }
-    const bool f64 = precision != AGX_PHMM_F32;
+    const bool f64 = precision == AGX_PHMM_F64 || precision == AGX_PHMM_F64_FMA;
+    // the packed float kernel spans at most 64 lanes x 30 columns: one longer haplotype moves the whole
+    // batch to the order-exact float kernel (same tolerance, AGX_PHMM_F32 semantics)
+    if (precision == AGX_PHMM_F32_FMA) {
+        for (uint32_t h = 0; h < d->n_haps && d->hap_off; ++h)
+            if (d->hap_off[h + 1] - d->hap_off[h] > 64u * 30u) {
+                precision = AGX_PHMM_F32;
+                break;
+            }
+    }
+    const bool packed = precision == AGX_PHMM_F32_FMA;
     const bool probs = prob != nullptr;
     if (probs && precision != AGX_PHMM_F64) {
         agx_set_error("probability tracks are only supported with AGX_PHMM_F64");
@@ -167,10 +182,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    // ---- plan
-    std::vector<Plan> gen; // in output order: region, read, haplotype
+    // ---- enumerate the pairs in output order: region, read, haplotype
+    std::vector<Plan> gen0;
     int64_t n_pairs = 0, cells = 0;
-    std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
     for (uint32_t g = 0; g < d->n_regions; ++g) {
         const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
         const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
@@ -195,72 +209,27 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 p.hap = h;
                 p.R = (uint32_t)R;
                 p.H = (uint32_t)H;
-                const uint32_t key = (uint32_t)R << 16 | (uint32_t)H;
-                auto it = memo.find(key);
-                if (it == memo.end()) {
-                    choose_tiling(precision, p.R, p.H, &p.cls, &p.G);
-                    it = memo.emplace(key, (uint16_t)(p.cls << 8 | p.G)).first;
-                }
-                p.cls = (uint8_t)(it->second >> 8);
-                p.G = (uint8_t)(it->second & 0xff);
-                if (p.cls >= kPhNumClasses) {
-                    agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", r, h, p.H);
-                    return AGX_E_LIMIT;
-                }
-                gen.push_back(p);
+                gen0.push_back(p);
             }
         }
-        if (n_pairs > 0x7fffffffLL) {
+        if (n_pairs > 0x7ffffff0LL) {
             agx_set_error("more than 2^31 pairs in one batch");
             return AGX_E_LIMIT;
         }
     }
-    // dominant (R, H) shape?
-    if (gen.size() >= 1024 && n_cu > 0) {
-        const size_t stride = gen.size() / 512;
-        uint32_t cand = 0;
-        int votes = 0;
-        for (size_t k = 0; k < 512; ++k) {
-            const Plan &p = gen[k * stride];
-            const uint32_t key = p.R << 16 | p.H;
-            if (votes == 0) {
-                cand = key;
-                votes = 1;
-            } else
-                votes += key == cand ? 1 : -1;
-        }
-        int64_t count = 0;
-        for (const Plan &p : gen)
-            if ((p.R << 16 | p.H) == cand) ++count;
-        if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
-            uint8_t c = 255, G = 0;
-            choose_tiling_uniform(precision, cand >> 16, cand & 0xffffu, count, 4 * n_cu, &c, &G);
-            if (c < kPhNumClasses)
-                for (Plan &p : gen)
-                    if ((p.R << 16 | p.H) == cand) {
-                        p.cls = c;
-                        p.G = G;
-                    }
+    if (!gen0.empty()) {
+        if (!d->read_bases || !d->hap_bases || (!probs && (!d->q_base || !d->q_ins || !d->q_del || !d->q_gcp))) {
+            agx_set_error("agx_phmm_batch_create: NULL track");
+            return AGX_E_ARG;
         }
     }
-    // order: class, lanes per group (wide first), then read, haplotype -- haplotypes of one read stay
-    // adjacent (one LDS table).  `gen` is already (read, haplotype)-ordered: one stable counting pass.
-    std::vector<Plan> plan(gen.size());
-    {
-        std::vector<uint32_t> cnt((size_t)kPhNumClasses * 64 + 1, 0);
-        auto bucket = [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); };
-        for (const Plan &p : gen) ++cnt[bucket(p) + 1];
-        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-        for (const Plan &p : gen) plan[cnt[bucket(p)]++] = p;
-    }
-    std::vector<Plan>().swap(gen);
-    const double t_plan = now();
 
-    // ---- image: every read and haplotype once
+    // ---- image: every read and haplotype once, shared by all plans of the batch
     std::vector<uint32_t> img;
+    img.resize((64 * 30 + 8) / 4, 0u); // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 30 columns)
     std::vector<uint32_t> read_dw(d->n_reads, 0xffffffffu), hap_dw(d->n_haps, 0xffffffffu);
-    auto put_read = [&](uint32_t r) -> int {
-        if (read_dw[r] != 0xffffffffu) return 0;
+    auto put_read = [&](uint32_t r) {
+        if (read_dw[r] != 0xffffffffu) return;
         const uint64_t o = d->read_off[r];
         const uint32_t R = (uint32_t)(d->read_off[r + 1] - o);
         const size_t trk = ((size_t)R + 3) / 4;
@@ -278,7 +247,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             const uint8_t *src[5] = {d->read_bases, d->q_base, d->q_ins, d->q_del, d->q_gcp};
             for (int k = 0; k < 5; ++k) memcpy(p + (size_t)k * trk * 4, src[k] + o, R);
         }
-        return 0;
     };
     auto put_hap = [&](uint32_t h) {
         if (hap_dw[h] != 0xffffffffu) return;
@@ -288,77 +256,166 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         img.resize(img.size() + ((size_t)H + kHapSlack + 3) / 4, 0u);
         memcpy(reinterpret_cast<uint8_t *>(&img[hap_dw[h]]), d->hap_bases + o, H);
     };
-    if (!plan.empty()) {
-        if (!d->read_bases || !d->hap_bases || (!probs && (!d->q_base || !d->q_ins || !d->q_del || !d->q_gcp))) {
-            agx_set_error("agx_phmm_batch_create: NULL track");
-            return AGX_E_ARG;
-        }
-    }
 
-    // ---- waves
-    std::vector<PhGroup> groups(plan.size());
-    std::vector<PhTab> tabs;
-    std::vector<PhWave> waves;
-    std::vector<ClassLaunch> launches;
-    int64_t padded = 0;
-    size_t i = 0;
-    while (i < plan.size()) {
-        const int cls = plan[i].cls;
-        ClassLaunch cl;
-        cl.C = kPhClasses[cls];
-        cl.first_wave = (uint32_t)waves.size();
-        while (i < plan.size() && plan[i].cls == cls) {
-            const int G = plan[i].G;
-            const int per_wave = 64 / G;
-            PhWave w{};
-            w.first_group = (uint32_t)i;
-            w.first_tab = (uint32_t)tabs.size();
-            w.G = (uint16_t)G;
-            int n = 0;
-            uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
-            while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
-                const Plan &p = plan[i];
-                const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
-                const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                if (n > 0 && ntabs_new > 1 && ph_tab_bytes(f64, gatk_prior, nsteps + G - 1) * ntabs_new > kTabBudget) break;
-                if (p.read != last_read) {
-                    put_read(p.read);
-                    tabs.push_back(PhTab{read_dw[p.read], p.R});
-                    last_read = p.read;
-                }
-                put_hap(p.hap);
-                if (img.size() > 0xfffffff0ull) {
-                    agx_set_error("packed image exceeds 16 GiB; split the batch");
-                    return AGX_E_LIMIT;
-                }
-                ntabs = ntabs_new;
-                steps = nsteps;
-                PhGroup g{};
-                g.hap_dw = hap_dw[p.hap];
-                g.H = p.H;
-                g.R_tab = p.R | ((ntabs - 1) << 16);
-                g.out = p.out;
-                g.init64 = DBL_MAX / 16 / (double)p.H;
-                g.init32 = FLT_MAX / 16 / (float)p.H;
-                groups[i] = g;
-                ++n;
-                ++i;
+    // ---- a plan: lane tilings, waves and records for one kernel family.
+    // kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group.
+    struct PlanOut {
+        std::vector<PhGroup> groups1;
+        std::vector<PhGroup2> groups2;
+        std::vector<PhTab> tabs;
+        std::vector<PhWave> waves;
+        std::vector<ClassLaunch> launches;
+        int64_t padded = 0;
+    };
+    auto make_plan = [&](int kind, int slots, bool rows_f64, PlanOut &po) -> int {
+        std::vector<Plan> gen = gen0;
+        std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
+        for (Plan &p : gen) {
+            const uint32_t key = p.R << 16 | p.H;
+            auto it = memo.find(key);
+            if (it == memo.end()) {
+                uint8_t c = 255, G = 0;
+                choose_tiling(kind, p.R, p.H, &c, &G);
+                it = memo.emplace(key, (uint16_t)(c << 8 | G)).first;
             }
-            w.n_groups = (uint16_t)n;
-            w.n_tabs = (uint16_t)ntabs;
-            w.steps = steps;
-            cl.lds = std::max(cl.lds, ph_tab_bytes(f64, gatk_prior, steps + G - 1) * ntabs);
-            cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
-            padded += (int64_t)steps * 64 * cl.C;
-            waves.push_back(w);
+            p.cls = (uint8_t)(it->second >> 8);
+            p.G = (uint8_t)(it->second & 0xff);
+            if (p.cls >= kPhNumClasses) {
+                agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", p.read, p.hap, p.H);
+                return AGX_E_LIMIT;
+            }
         }
-        cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
-        if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
-            agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
-            return AGX_E_LIMIT;
+        // dominant (R, H) shape?
+        if (gen.size() >= 1024 && n_cu > 0) {
+            const size_t stride = gen.size() / 512;
+            uint32_t cand = 0;
+            int votes = 0;
+            for (size_t k = 0; k < 512; ++k) {
+                const Plan &p = gen[k * stride];
+                const uint32_t key = p.R << 16 | p.H;
+                if (votes == 0) {
+                    cand = key;
+                    votes = 1;
+                } else
+                    votes += key == cand ? 1 : -1;
+            }
+            int64_t count = 0;
+            for (const Plan &p : gen)
+                if ((p.R << 16 | p.H) == cand) ++count;
+            if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
+                uint8_t c = 255, G = 0;
+                choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count + slots - 1) / slots, 4 * n_cu, &c, &G);
+                if (c < kPhNumClasses)
+                    for (Plan &p : gen)
+                        if ((p.R << 16 | p.H) == cand) {
+                            p.cls = c;
+                            p.G = G;
+                        }
+            }
         }
-        launches.push_back(cl);
-    }
+        // order: class, lanes per group (wide first), then read, haplotype -- haplotypes of one read stay
+        // adjacent (one LDS table).  `gen` is already (read, haplotype)-ordered: one stable counting pass.
+        std::vector<Plan> plan(gen.size());
+        {
+            std::vector<uint32_t> cnt((size_t)kPhNumClasses * 64 + 1, 0);
+            auto bucket = [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); };
+            for (const Plan &p : gen) ++cnt[bucket(p) + 1];
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            for (const Plan &p : gen) plan[cnt[bucket(p)]++] = p;
+        }
+        std::vector<Plan>().swap(gen);
+        size_t i = 0;
+        while (i < plan.size()) {
+            const int cls = plan[i].cls;
+            ClassLaunch cl;
+            cl.C = kPhClasses[cls];
+            cl.first_wave = (uint32_t)po.waves.size();
+            while (i < plan.size() && plan[i].cls == cls) {
+                const int G = plan[i].G;
+                const int per_wave = 64 / G;
+                PhWave w{};
+                w.first_group = (uint32_t)(slots == 2 ? po.groups2.size() : po.groups1.size());
+                w.first_tab = (uint32_t)po.tabs.size();
+                w.G = (uint16_t)G;
+                int n = 0;
+                uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
+                while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
+                    const Plan &p = plan[i];
+                    const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
+                    const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
+                    if (n > 0 && ntabs_new > 1 && ph_tab_bytes(rows_f64, gatk_prior, nsteps + G - 1) * ntabs_new > kTabBudget) break;
+                    if (p.read != last_read) {
+                        put_read(p.read);
+                        po.tabs.push_back(PhTab{read_dw[p.read], p.R});
+                        last_read = p.read;
+                    }
+                    ntabs = ntabs_new;
+                    steps = nsteps;
+                    put_hap(p.hap);
+                    if (slots == 2) {
+                        PhGroup2 g{};
+                        g.R_tab = p.R | ((ntabs - 1) << 16);
+                        g.hap_dw[0] = hap_dw[p.hap];
+                        g.H[0] = p.H;
+                        g.out[0] = p.out;
+                        g.init32[0] = FLT_MAX / 16 / (float)p.H;
+                        // second slot: the next haplotype of the same read in this class, else vacant
+                        g.hap_dw[1] = 0;
+                        g.H[1] = 0;
+                        g.out[1] = (uint32_t)n_pairs;
+                        g.init32[1] = 0;
+                        if (i + 1 < plan.size() && plan[i + 1].cls == cls && plan[i + 1].G == G && plan[i + 1].read == p.read) {
+                            const Plan &q = plan[i + 1];
+                            put_hap(q.hap);
+                            g.hap_dw[1] = hap_dw[q.hap];
+                            g.H[1] = q.H;
+                            g.out[1] = q.out;
+                            g.init32[1] = FLT_MAX / 16 / (float)q.H;
+                            ++i;
+                        }
+                        po.groups2.push_back(g);
+                    } else {
+                        PhGroup g{};
+                        g.hap_dw = hap_dw[p.hap];
+                        g.H = p.H;
+                        g.R_tab = p.R | ((ntabs - 1) << 16);
+                        g.out = p.out;
+                        g.init64 = DBL_MAX / 16 / (double)p.H;
+                        g.init32 = FLT_MAX / 16 / (float)p.H;
+                        po.groups1.push_back(g);
+                    }
+                    if (img.size() > 0xfffffff0ull) {
+                        agx_set_error("packed image exceeds 16 GiB; split the batch");
+                        return AGX_E_LIMIT;
+                    }
+                    ++n;
+                    ++i;
+                }
+                w.n_groups = (uint16_t)n;
+                w.n_tabs = (uint16_t)ntabs;
+                w.steps = steps;
+                cl.lds = std::max(cl.lds, ph_tab_bytes(rows_f64, gatk_prior, steps + G - 1) * ntabs);
+                cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
+                po.padded += (int64_t)steps * 64 * cl.C * slots;
+                po.waves.push_back(w);
+            }
+            cl.n_waves = (uint32_t)po.waves.size() - cl.first_wave;
+            if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
+                agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
+                return AGX_E_LIMIT;
+            }
+            po.launches.push_back(cl);
+        }
+        return AGX_OK;
+    };
+
+    PlanOut pmain, presc;
+    rc = make_plan(precision, packed ? 2 : 1, f64, pmain);
+    // a packed float batch cannot reuse its records for the double rescue pass: second plan
+    if (!rc && packed) rc = make_plan(AGX_PHMM_F64, 1, true, presc);
+    if (rc) return rc;
+    const double t_plan = now();
+    const int64_t padded = pmain.padded;
 
     const double t_pack = now();
     // ---- upload
@@ -367,15 +424,20 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->precision = precision;
     b->probs = probs;
     b->gatk_prior = gatk_prior;
+    b->packed = packed;
+    b->separate_rescue = packed;
     b->n_pairs = n_pairs;
-    b->launches = launches;
+    b->main.launches = pmain.launches;
+    b->rescue.launches = presc.launches;
+    const size_t groups_bytes = packed ? pmain.groups2.size() * sizeof(PhGroup2) : pmain.groups1.size() * sizeof(PhGroup);
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
     b->info.padded_cells = padded;
-    b->info.input_bytes = (int64_t)(img.size() * 4 + groups.size() * sizeof(PhGroup) + tabs.size() * sizeof(PhTab) +
-                                    waves.size() * sizeof(PhWave));
-    b->info.n_launches = (int32_t)launches.size() * (precision == AGX_PHMM_F32 ? 2 : 1);
-    b->info.n_waves = (int32_t)waves.size();
+    b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + pmain.tabs.size() * sizeof(PhTab) +
+                                    pmain.waves.size() * sizeof(PhWave));
+    const bool two_pass = precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA;
+    b->info.n_launches = (int32_t)(pmain.launches.size() + (packed ? presc.launches.size() : two_pass ? pmain.launches.size() : 0));
+    b->info.n_waves = (int32_t)pmain.waves.size();
     if (!ctx) { // planning only
         *out = b;
         return AGX_OK;
@@ -384,10 +446,13 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     float lut_f[256], mis_f[256];
     build_lut(gatk_prior, lut_d, lut_f, mis_d, mis_f);
     rc = b->img.alloc(img.size() * 4);
-    if (!rc) rc = b->groups.alloc(groups.size() * sizeof(PhGroup));
-    if (!rc) rc = b->tabs.alloc(tabs.size() * sizeof(PhTab));
-    if (!rc) rc = b->waves.alloc(waves.size() * sizeof(PhWave));
-    if (!rc) rc = b->sums.alloc((size_t)n_pairs * sizeof(double));
+    if (!rc) rc = b->main.groups.alloc(groups_bytes);
+    if (!rc) rc = b->main.tabs.alloc(pmain.tabs.size() * sizeof(PhTab));
+    if (!rc) rc = b->main.waves.alloc(pmain.waves.size() * sizeof(PhWave));
+    if (!rc && packed) rc = b->rescue.groups.alloc(presc.groups1.size() * sizeof(PhGroup));
+    if (!rc && packed) rc = b->rescue.tabs.alloc(presc.tabs.size() * sizeof(PhTab));
+    if (!rc && packed) rc = b->rescue.waves.alloc(presc.waves.size() * sizeof(PhWave));
+    if (!rc) rc = b->sums.alloc(((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->lut.alloc(2 * (sizeof lut_d + sizeof lut_f)); // [lut_d][lut_f][mis_d][mis_f]
     if (!rc) rc = b->counter.alloc(sizeof(unsigned long long));
     if (rc) {
@@ -399,9 +464,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         if (e == hipSuccess && n) e = hipMemcpy(dst.p, src, n, hipMemcpyHostToDevice);
     };
     up(b->img, img.data(), img.size() * 4);
-    up(b->groups, groups.data(), groups.size() * sizeof(PhGroup));
-    up(b->tabs, tabs.data(), tabs.size() * sizeof(PhTab));
-    up(b->waves, waves.data(), waves.size() * sizeof(PhWave));
+    up(b->main.groups, packed ? (const void *)pmain.groups2.data() : (const void *)pmain.groups1.data(), groups_bytes);
+    up(b->main.tabs, pmain.tabs.data(), pmain.tabs.size() * sizeof(PhTab));
+    up(b->main.waves, pmain.waves.data(), pmain.waves.size() * sizeof(PhWave));
+    if (packed) {
+        up(b->rescue.groups, presc.groups1.data(), presc.groups1.size() * sizeof(PhGroup));
+        up(b->rescue.tabs, presc.tabs.data(), presc.tabs.size() * sizeof(PhTab));
+        up(b->rescue.waves, presc.waves.data(), presc.waves.size() * sizeof(PhWave));
+    }
     up(b->lut, lut_d, sizeof lut_d);
     if (e == hipSuccess) e = hipMemcpy((char *)b->lut.p + sizeof lut_d, lut_f, sizeof lut_f, hipMemcpyHostToDevice);
     if (e == hipSuccess)
@@ -431,9 +501,11 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     b->img.release();
-    b->groups.release();
-    b->tabs.release();
-    b->waves.release();
+    for (agx_phmm_batch::DevPlan *pl : {&b->main, &b->rescue}) {
+        pl->groups.release();
+        pl->tabs.release();
+        pl->waves.release();
+    }
     b->sums.release();
     b->lut.release();
     b->counter.release();
@@ -462,36 +534,63 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     const void *lut_f = (const char *)b->lut.p + 256 * sizeof(double);
     const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
     const void *mis_f = (const char *)b->lut.p + 256 * (2 * sizeof(double) + sizeof(float));
-    const int passes = b->precision == AGX_PHMM_F32 ? 2 : 1;
-    if (passes == 2) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
-    // the counter reset above is ordered before the fork; each class's fill and (F32) its double
-    // rescue pass share a stream, different classes run side by side
-    FanOut fan(b->ctx, (int)b->launches.size());
-    rc = fan.begin();
-    if (rc) return rc;
-    int k = 0;
-    for (const ClassLaunch &cl : b->launches) {
-        hipStream_t st = fan.stream(k++);
-        for (int pass = 0; pass < passes; ++pass) {
-            // F32: pass 0 = float fill, pass 1 = double recomputation of the pairs that underflowed
-            int mode = b->precision;
-            if (b->probs) mode = 4;
-            if (pass == 1) mode = 3;
-            const bool f64 = mode != 2;
-            const size_t lds = pass == 1 ? cl.lds_rescue : cl.lds; // same records, wider table rows
-            const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->groups.p,
-                                                (const PhTab *)b->tabs.p, (const PhWave *)b->waves.p + cl.first_wave,
-                                                cl.n_waves, f64 ? lut_d : lut_f, b->gatk_prior ? (f64 ? mis_d : mis_f) : nullptr,
-                                                (double *)b->sums.p,
-                                                (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, st);
-            if (r) {
-                agx_set_error("phmm_fill<C=%d, mode %d> launch failed: %s", cl.C, mode, hipGetErrorString(hipGetLastError()));
-                return AGX_E_HIP;
+    const bool f32_family = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
+    if (f32_family) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
+    const void *mis_for_d = b->gatk_prior ? mis_d : nullptr, *mis_for_f = b->gatk_prior ? mis_f : nullptr;
+    auto launch_scalar = [&](const agx_phmm_batch::DevPlan &pl, const ClassLaunch &cl, int mode, hipStream_t st) -> int {
+        const bool f64 = mode != 2;
+        const size_t lds = mode == 3 && !b->separate_rescue ? cl.lds_rescue : cl.lds; // same records, wider table rows
+        const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)pl.groups.p,
+                                            (const PhTab *)pl.tabs.p, (const PhWave *)pl.waves.p + cl.first_wave, cl.n_waves,
+                                            f64 ? lut_d : lut_f, f64 ? mis_for_d : mis_for_f, (double *)b->sums.p,
+                                            (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, st);
+        if (r) {
+            agx_set_error("phmm_fill<C=%d, mode %d> launch failed: %s", cl.C, mode, hipGetErrorString(hipGetLastError()));
+            return AGX_E_HIP;
+        }
+        return AGX_OK;
+    };
+    // the counter reset above is ordered before the fork; different classes run side by side
+    {
+        FanOut fan(b->ctx, (int)b->main.launches.size());
+        rc = fan.begin();
+        if (rc) return rc;
+        int k = 0;
+        for (const ClassLaunch &cl : b->main.launches) {
+            hipStream_t st = fan.stream(k++);
+            if (b->packed) {
+                const int r = agx_phmm_pk_launch_class(cl.C, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                                                       (const PhTab *)b->main.tabs.p,
+                                                       (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
+                                                       mis_for_f, (double *)b->sums.p, cl.lds, st);
+                if (r) {
+                    agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
+                    return AGX_E_HIP;
+                }
+            } else {
+                int mode = b->precision;
+                if (b->probs) mode = 4;
+                rc = launch_scalar(b->main, cl, mode, st);
+                // AGX_PHMM_F32: the double recomputation of underflowed pairs reuses the class's records
+                if (!rc && b->precision == AGX_PHMM_F32) rc = launch_scalar(b->main, cl, 3, st);
+                if (rc) return rc;
             }
         }
+        rc = fan.end();
+        if (rc) return rc;
     }
-    rc = fan.end();
-    if (rc) return rc;
+    if (b->separate_rescue) { // packed float fill done on every stream: now the double rescue plan
+        FanOut fan(b->ctx, (int)b->rescue.launches.size());
+        rc = fan.begin();
+        if (rc) return rc;
+        int k = 0;
+        for (const ClassLaunch &cl : b->rescue.launches) {
+            rc = launch_scalar(b->rescue, cl, 3, fan.stream(k++));
+            if (rc) return rc;
+        }
+        rc = fan.end();
+        if (rc) return rc;
+    }
     return AGX_OK;
 }
 
@@ -520,7 +619,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     b->info.n_rescued = (int64_t)nres;
     // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
-    const bool f32 = b->precision == AGX_PHMM_F32;
+    const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
     agx_parallel_for(b->n_pairs, 8192, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             double v = s[k];

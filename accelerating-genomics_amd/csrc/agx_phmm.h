@@ -17,6 +17,18 @@ struct PhGroup {
     uint32_t reserved;
 };
 
+// Packed float kernel (AGX_PHMM_F32_FMA): one group of G lanes carries two haplotypes of the same
+// read ([0] in the x half, [1] in the y half of every float2).  A group without a second haplotype
+// points [1] at an empty haplotype (H = 0) and at the spare slot sums[n_pairs].
+struct PhGroup2 {
+    uint32_t hap_dw[2];
+    uint32_t H[2];
+    uint32_t out[2];
+    float init32[2];
+    uint32_t R_tab; // R | tab << 16
+    uint32_t reserved;
+};
+
 // One read table to build in LDS: the read's five tracks start at read_dw, each padded to 4 bytes.
 struct PhTab {
     uint32_t read_dw;
@@ -37,15 +49,18 @@ struct PhWave {
 
 #define AGX_PH_FOR_EACH_CLASS(X) \
     X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
+// classes of the packed float kernel: six state registers per column, so at most 30 columns
+#define AGX_PH_FOR_EACH_PK_CLASS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30)
 static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic
 // (MI355X, tools/calibrate_classes.py, profiles/r01_calibration*.log); 0 = class not built
-// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.
-static const double kPhClassCost[3][19] = {
+// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32, packed f32 FMA.
+static const double kPhClassCost[4][19] = {
     {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.220, 0, 0, 0, 0},
     {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 1.211, 0, 0, 0, 0},
     {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
+    {1.975, 1.544, 1.343, 1.230, 1.176, 1.105, 1.071, 1.067, 1.033, 1.029, 1.004, 1.000, 1.146, 1.142, 0, 0, 0, 0, 0},
 };
 
 // bytes of LDS one table row takes: Qr, Qi, Qd, Qg (+ a separate mismatch prior when it is not
@@ -59,6 +74,9 @@ __host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, ui
 // mode: 0 = f64 reference order, 1 = f64 with FMA contraction, 2 = f32, 3 = f64 rescue pass
 // over an f32 result (only groups whose sums[out] < rescue_below are recomputed), 4 = f64
 // reference order with probability tracks instead of Phred characters (pairHMM() seam).
+int agx_phmm_pk_launch_class(int cols_per_lane, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
+                             const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
+                             size_t lds_bytes, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
                           const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                           double rescue_below,

@@ -1,0 +1,241 @@
+// PairHMM forward recurrence, packed float variant (AGX_PHMM_F32_FMA): the schedule of
+// agx_phmm_kernel.hip -- haplotype columns across a group of G lanes, read rows streaming skewed,
+// neighbours by DPP, per-read probability table in LDS -- but every lane group carries TWO
+// haplotypes of the same read, one in each half of a float2, and the cell runs on packed fp32
+// instructions with FMA contraction:
+//     t = gm * (X_d + Y_d)            v_pk_add_f32, v_pk_mul_f32
+//     M = prior * fma(mm, M_d, t)     v_pk_fma_f32, v_pk_mul_f32     (antidiagsPairHMM.c:184)
+//     X = fma(M_up, Qi, X_up * Qg)    v_pk_mul_f32, v_pk_fma_f32     (:189)
+//     Y = fma(M_left, Qd, Y_left*Qg)  v_pk_mul_f32, v_pk_fma_f32     (:194)
+// = 8 packed instructions + 2 compares + 2 selects per 2 cells, against 11 + 2 scalar ones per cell
+// in the order-exact float kernel; v_pk_*_f32 issue at 75 T elements/s on this chip where
+// v_mul/v_add_f32 reach 65 and v_fma_f32 42 (tools/valu_microbench.hip), and
+// tools/phmm_mix_microbench.hip measured the two cell loops at 0.17 vs 0.32 ps/cell.
+//
+// Numerics: float with the initial constant FLT_MAX/16 like AGX_PHMM_F32, but contracted -- not
+// bit-identical to the oracle's float restatement; the bar is BASELINE config 3's 1e-6 relative on
+// the log10 likelihood (tests/test_phmm_gpu.py).  Pairs whose float sum underflows are recomputed
+// by the double kernel (its own plan, RESCUE mode) exactly as for AGX_PHMM_F32.
+#include "agx_phmm.h"
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int shr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); } // wave_shr:1
+__device__ __forceinline__ f2 shr1(f2 v)
+{
+    return f2{__int_as_float(shr1i(__float_as_int(v.x))), __int_as_float(shr1i(__float_as_int(v.y)))};
+}
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int C>
+__global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
+                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                                   uint32_t n_waves, const float *__restrict__ lut,
+                                                   const float *__restrict__ lut_mis, double *__restrict__ sums)
+{
+    constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t wave = blockIdx.x; // one wavefront per workgroup
+    if (wave >= n_waves) return;
+    const int lane = threadIdx.x;
+    const PhWave w = waves[wave];
+    const int G = w.G;
+    const int grp = lane / G;
+    const int gl = lane - grp * G;
+    const bool active = grp < (int)w.n_groups;
+    const bool start = gl == 0;
+
+    PhGroup2 g;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        g.hap_dw[k] = g.H[k] = g.out[k] = 0;
+        g.init32[k] = 0;
+    }
+    g.R_tab = 0;
+    if (active) g = groups[w.first_group + grp];
+    const int R = (int)(g.R_tab & 0xffffu);
+    const int HA = (int)g.H[0], HB = (int)g.H[1];
+
+    // ---- read tables -> LDS (as in agx_phmm_kernel.hip, float rows)
+    const uint32_t rows = w.steps + (uint32_t)G - 1u;
+    const bool mis_col = lut_mis != nullptr;
+    const uint32_t ncol = mis_col ? 5u : 4u;
+    const size_t tab_bytes = ph_tab_bytes(false, mis_col, rows);
+    for (uint32_t k = 0; k < w.n_tabs; ++k) {
+        const PhTab tb = tabs[w.first_tab + k];
+        float *tq = reinterpret_cast<float *>(lds + k * tab_bytes);
+        unsigned char *tc = reinterpret_cast<unsigned char *>(tq + ncol * rows);
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
+        const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
+        for (uint32_t r = lane; r < rows; r += 64) {
+            const int i = (int)r - (G - 1);
+            float vr = 0, vi = 0, vd = 0, vg = 1, vm = 0; // neutral row
+            unsigned char c = 0;
+            if (i >= 0 && i < (int)tb.R) {
+                c = rp[i];
+                vr = lut[rp[trk + i]];
+                if (mis_col) vm = lut_mis[rp[trk + i]];
+                vi = lut[rp[2 * trk + i]];
+                vd = lut[rp[3 * trk + i]];
+                vg = lut[rp[4 * trk + i]];
+            }
+            tq[r] = vr;
+            tq[rows + r] = vi;
+            tq[2 * rows + r] = vd;
+            tq[3 * rows + r] = vg;
+            if (mis_col) tq[4 * rows + r] = vm;
+            tc[r] = c;
+        }
+    }
+    __syncthreads();
+
+    const uint32_t mis_off = mis_col ? 4u * rows : 0u;
+    const uint32_t tabi = g.R_tab >> 16;
+    const float *tq = reinterpret_cast<const float *>(lds + tabi * tab_bytes) + (G - 1 - gl);
+    const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + ncol * rows * sizeof(float)) + (G - 1 - gl);
+
+    // this lane's C bases of both haplotypes
+    uint32_t ha[HW], hb[HW];
+    {
+        const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
+        uint32_t ra[HW + 1], rb[HW + 1];
+#pragma unroll
+        for (int k = 0; k <= HW; ++k) {
+            ra[k] = active ? img[g.hap_dw[0] + d0 + k] : 0u;
+            rb[k] = active ? img[g.hap_dw[1] + d0 + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < HW; ++k) {
+            ha[k] = __builtin_amdgcn_alignbyte(ra[k + 1], ra[k], sh);
+            hb[k] = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
+        }
+    }
+    // haplotype 'N' matches every read base (:111-113); rare, so the cell loop exists twice
+    unsigned long long na = 0, nb = 0;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        na |= (((ha[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N' ? 1ull : 0ull) << j;
+        nb |= (((hb[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N' ? 1ull : 0ull) << j;
+    }
+
+    const f2 init = f2{g.init32[0], g.init32[1]};
+    f2 M[C], X[C], Y[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        M[j] = splat(0.f);
+        X[j] = splat(0.f);
+        Y[j] = init;
+    }
+    f2 pM = splat(0.f), pX = splat(0.f), pY = init;
+    f2 acc_prev = splat(0.f), result = splat(0.f);
+    const int steps = (int)w.steps;
+    const int col0 = gl * C;
+
+    auto fill = [&](auto hapn_tag) {
+        constexpr bool HAPN = decltype(hapn_tag)::value;
+        for (int t = 0; t < steps; ++t) {
+            const float q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
+            const float q_m = tq[mis_off + t];
+            const uint32_t rc = tc[t];
+            const float pm = 1 - q_r;                        // p(): match or N
+            const float pq = rc == (uint32_t)'N' ? pm : q_m; //      mismatch
+            const f2 mm = splat(1 - (q_i + q_d)), gm = splat(1 - q_g);
+            const f2 qi = splat(q_i), qd = splat(q_d), qg = splat(q_g);
+
+            f2 lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
+            f2 acc = shr1(acc_prev);
+            if (start) { // column 0 of rows >= 1 (:168-178)
+                lM = splat(0.f);
+                lX = splat(0.f);
+                lY = splat(0.f);
+                acc = splat(0.f);
+            }
+            const f2 dM0 = pM, dX0 = pX, dY0 = pY;
+            pM = lM;
+            pX = lX;
+            pY = lY;
+            // pass A, right to left: M and X in place
+#pragma unroll
+            for (int j = C - 1; j >= 0; --j) {
+                const uint32_t ca = (ha[j >> 2] >> (8 * (j & 3))) & 0xffu, cb = (hb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                bool ma = ca == rc, mb = cb == rc;
+                if constexpr (HAPN) {
+                    ma = ma || ((na >> j) & 1ull);
+                    mb = mb || ((nb >> j) & 1ull);
+                }
+                const f2 prior = f2{ma ? pm : pq, mb ? pm : pq};
+                const f2 dM = j ? M[j > 0 ? j - 1 : 0] : dM0;
+                const f2 dX = j ? X[j > 0 ? j - 1 : 0] : dX0;
+                const f2 dY = j ? Y[j > 0 ? j - 1 : 0] : dY0;
+                const f2 x = fma2(M[j], qi, X[j] * qg);
+                const f2 m = prior * fma2(mm, dM, gm * (dX + dY));
+                X[j] = x;
+                M[j] = m;
+            }
+            // pass B, left to right: Y needs the new M and Y of column j-1
+            f2 cM = lM, cY = lY;
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                const f2 y = fma2(cM, qd, cY * qg);
+                cM = M[j];
+                cY = y;
+                Y[j] = y;
+            }
+            if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    if (col0 + j < HA) acc.x += (M[j].x + X[j].x);
+                    if (col0 + j < HB) acc.y += (M[j].y + X[j].y);
+                }
+                if (gl == G - 1) result = acc;
+            }
+            acc_prev = acc;
+        }
+    };
+    if (__any((na | nb) != 0))
+        fill(std::true_type{});
+    else
+        fill(std::false_type{});
+
+    if (active && gl == G - 1) {
+        sums[g.out[0]] = (double)result.x;
+        sums[g.out[1]] = (double)result.y; // a group without a second haplotype points this at the spare slot
+    }
+}
+
+template <int C>
+int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
+           const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
+{
+    auto k = phmm_fill_pk<C>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -1;
+    }
+    hipLaunchKernelGGL(k, dim3(n_waves), dim3(64), lds, s, img, groups, tabs, waves, n_waves, (const float *)lut,
+                       (const float *)lut_mis, sums);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace
+
+int agx_phmm_pk_launch_class(int cols_per_lane, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
+                             const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
+                             size_t lds_bytes, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    switch (cols_per_lane) {
+#define AGX_PH_PK_CASE(CC) \
+    case CC: return launch<CC>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
+        AGX_PH_FOR_EACH_PK_CLASS(AGX_PH_PK_CASE)
+#undef AGX_PH_PK_CASE
+    default: return -2;
+    }
+}

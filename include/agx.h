@@ -163,6 +163,9 @@ typedef struct agx_phmm_desc {
 #define AGX_PHMM_F32 2      /* float with initial constant FLT_MAX/16 (BASELINE config 3);
                                pairs whose float sum falls below AGX_PHMM_F32_RESCUE are
                                recomputed with AGX_PHMM_F64 on the device */
+#define AGX_PHMM_F32_FMA 3  /* float, two haplotypes per lane group on packed FMA instructions: the fastest
+                               mode; <= 1e-6 relative on log10 like AGX_PHMM_F32 but not bit-identical to a
+                               plain float evaluation; same double rescue of underflowing pairs */
 #define AGX_PHMM_F32_RESCUE 1e-28f
 /* OR-able into `precision` (8f n4, default off): mismatch prior Qr/3 as GATK's PairHMM uses, instead
  * of the reference's Qr (antidiagsPairHMM.c:111-113).  Not a behaviour of the

@@ -50,7 +50,7 @@ static void phmm_file(const char *dir, const char *name)
     int rc = agx_phmm_text_read(path, &t);
     EXPECT(rc == AGX_OK && t);
     if (!t) return;
-    for (int prec = 0; prec < 3; prec++) {
+    for (int prec = 0; prec < 4; prec++) {
         agx_phmm_batch *b = NULL;
         rc = agx_phmm_batch_create(NULL, &t->desc, prec | (prec == 1 ? AGX_PHMM_GATK_PRIOR : 0), &b);
         EXPECT(rc == AGX_OK && b);

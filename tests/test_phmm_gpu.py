@@ -58,9 +58,10 @@ def test_f64_fma_within_1e12(ctx, golden_dir, name):
 
 
 @pytest.mark.parametrize("name", NAMES)
-def test_f32_within_1e6_with_rescue(ctx, golden_dir, name):
+@pytest.mark.parametrize("prec", [agx.PHMM_F32, agx.PHMM_F32_FMA])
+def test_f32_within_1e6_with_rescue(ctx, golden_dir, name, prec):
     b, _, _ = agx.read_phmm_text(os.path.join(golden_dir, name + ".in"))
-    dev = ctx.phmm_batch(b, agx.PHMM_F32)
+    dev = ctx.phmm_batch(b, prec)
     dev.launch()
     got, _ = dev.results()
     assert np.all(np.isfinite(got))
@@ -97,6 +98,7 @@ def test_shapes_vs_oracle(ctx, oracle, shape):
     assert np.array_equal(s, s_ref) and np.array_equal(l, l_ref)
     dev.close()
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F32), l_ref) <= 1e-6
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA), l_ref) <= 1e-6
 
 
 def test_many_small_regions_and_table_sharing(ctx, oracle):
@@ -107,12 +109,13 @@ def test_many_small_regions_and_table_sharing(ctx, oracle):
     for p in parts:
         regions += _as_regions(p)
     b = synth.phmm_from_regions(regions)
-    s_ref, _ = oracle.phmm_batch(b, 0)
+    s_ref, l_ref = oracle.phmm_batch(b, 0)
     dev = ctx.phmm_batch(b)
     dev.launch()
     _, s = dev.results()
     assert np.array_equal(s, s_ref)
     dev.close()
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA), l_ref) <= 1e-6  # odd haplotype counts: vacant packed halves
 
 
 def _as_regions(p):
@@ -176,19 +179,20 @@ def test_relaunch_is_idempotent_and_info(ctx, oracle):
     dev.close()
 
 
-def test_full_size_config3_sample_and_linearity(ctx, oracle):
+@pytest.mark.parametrize("prec", [agx.PHMM_F32, agx.PHMM_F32_FMA])
+def test_full_size_config3_sample_and_linearity(ctx, oracle, prec):
     """BASELINE config 3 at full size (65 536 pairs, R=100, H=300, fp32).  The oracle checks a
     sample; the whole batch is checked through a size-independent property: results do not
     depend on how pairs are grouped into regions/waves (region order reversed => same values)."""
     b = synth.phmm_regions(64, 64, 16, 100, 300, seed=3)
     assert b.n_pairs == 65536
-    got = ctx.phmm_forward(b, agx.PHMM_F32)
+    got = ctx.phmm_forward(b, prec)
     sub = b.regions(5, 7)
     _, ref = oracle.phmm_batch(sub, 0)
     lo = 5 * 64 * 16
     assert relerr(got[lo : lo + ref.size], ref) <= 1e-6
     rev = synth.phmm_from_regions(_as_regions(b)[::-1])
-    got_rev = ctx.phmm_forward(rev, agx.PHMM_F32)
+    got_rev = ctx.phmm_forward(rev, prec)
     assert np.array_equal(got_rev.reshape(64, -1)[::-1].reshape(-1), got)
 
 
@@ -224,6 +228,8 @@ def test_largest_supported_shapes(ctx, oracle):
     got32 = ctx.phmm_forward(b, agx.PHMM_F32)
     assert relerr(got32, l_ref) <= 1e-6
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), l_ref) <= 1e-12
+    b2 = synth.phmm_regions(1, 2, 3, 4096, 1900, seed=78)  # packed float kernel: 64 lanes x 30 columns
+    assert relerr(ctx.phmm_forward(b2, agx.PHMM_F32_FMA), oracle.phmm_batch(b2, 0)[1]) <= 1e-6
 
 
 def test_gatk_prior_option(ctx, oracle, golden_dir):
@@ -238,4 +244,5 @@ def test_gatk_prior_option(ctx, oracle, golden_dir):
     assert np.array_equal(s, s_ref)
     assert not np.array_equal(l, g17(golden_dir, "phmm_10s"))
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F32 | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-6
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-6
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-12

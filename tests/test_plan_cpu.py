@@ -57,14 +57,14 @@ def test_planned_batch_cannot_run():
         p.scores()
 
 
-@pytest.mark.parametrize("prec", [agx.PHMM_F64, agx.PHMM_F64_FMA, agx.PHMM_F32])
+@pytest.mark.parametrize("prec", [agx.PHMM_F64, agx.PHMM_F64_FMA, agx.PHMM_F32, agx.PHMM_F32_FMA])
 def test_phmm_plans(prec):
     b = synth.phmm_regions(64, 64, 16, 100, 300, seed=3)
     p = agx.PhmmBatchDev(None, b, prec)
     i = p.info()
     assert i.n_pairs == 65536 and i.cells == b.cells() and i.padded_cells >= i.cells
     assert i.cells / i.padded_cells > (0.90 if prec == agx.PHMM_F32 else 0.80)
-    assert i.n_launches == (2 if prec == agx.PHMM_F32 else 1)
+    assert i.n_launches == (2 if prec in (agx.PHMM_F32, agx.PHMM_F32_FMA) else 1)
     with pytest.raises(agx.AgxError):
         p.launch()
     p.close()

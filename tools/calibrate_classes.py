@@ -28,14 +28,15 @@ if what == "sw":
     print("sw C=%%2d waves %%6d padded %%.3e ms %%.3f  ps/padded-cell %%.3f  GCUPS(real) %%.0f" %% (C, i.n_waves, i.padded_cells, ms, ms*1e9/i.padded_cells, i.cells/ms/1e6), flush=True)
 else:
     p = synth.phmm_regions(192, 32, 16, 128, 8*C, seed=2)
-    for prec, name in ((agx.PHMM_F32, "f32"), (agx.PHMM_F64, "f64"), (agx.PHMM_F64_FMA, "fma")):
+    for prec, name in ((agx.PHMM_F32, "f32"), (agx.PHMM_F64, "f64"), (agx.PHMM_F64_FMA, "fma"), (agx.PHMM_F32_FMA, "pkf")):
         if C > 32 and prec != agx.PHMM_F32: continue
+        if C > 30 and prec == agx.PHMM_F32_FMA: continue
         dev = ctx.phmm_batch(p, prec); i = dev.info(); ms = timeit(dev, 3)
         print("ph %%s C=%%2d waves %%6d padded %%.3e ms %%.3f  ps/padded-cell %%.3f  Mpairs/s %%.1f" %% (name, C, i.n_waves, i.padded_cells, ms, ms*1e9/i.padded_cells, p.n_pairs/ms/1e3), flush=True)
         dev.close()
 ''' % ROOT
 EVEN = tuple(range(4, 42, 2))
-for kern in ("pk", "i32"):
+for kern in (() if os.environ.get("CAL_ONLY_PH") else ("pk", "i32")):
     print("# SW kernel", kern, flush=True)
     for C in EVEN:
         subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="sw", CAL_C=str(C), AGX_SW_FORCE_C=str(C), AGX_SW_KERNEL=kern))

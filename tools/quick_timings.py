@@ -18,6 +18,6 @@ dev = ctx.sw_batch(b); info = dev.info(); ms = timeit(dev, 5)
 print("SW mixed 256k: %.3f ms %.0f GCUPS eff %.3f launches %d" % (ms, b.cells(False)/ms/1e6, info.cells/info.padded_cells, info.n_launches), flush=True); dev.close()
 for (nr,reads,haps,R,H,name,reps) in ((64,64,16,100,300,"C3",20),(64,32,16,250,500,"C5/8",8)):
     p = synth.phmm_regions(nr,reads,haps,R,H,seed=3)
-    for prec,pn in ((agx.PHMM_F32,"f32"),(agx.PHMM_F64,"f64"),(agx.PHMM_F64_FMA,"fma")):
+    for prec,pn in ((agx.PHMM_F32_FMA,"f32fma"),(agx.PHMM_F32,"f32"),(agx.PHMM_F64,"f64"),(agx.PHMM_F64_FMA,"fma")):
         dev = ctx.phmm_batch(p, prec); info = dev.info(); ms = timeit(dev, reps)
         print("PHMM %s %s: %.4f ms %.2f Mpairs/s eff %.3f waves %d" % (name, pn, ms, p.n_pairs/ms/1e3, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()
