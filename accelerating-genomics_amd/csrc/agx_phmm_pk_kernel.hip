@@ -101,8 +101,9 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
     const float *tq = reinterpret_cast<const float *>(lds + tabi * tab_bytes) + (G - 1 - gl);
     const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + ncol * rows * sizeof(float)) + (G - 1 - gl);
 
-    // this lane's C bases of both haplotypes
-    uint32_t ha[HW], hb[HW];
+    // this lane's C bases of both haplotypes, one register per column: a | b << 16
+    uint32_t hq[C];
+    unsigned long long na = 0, nb = 0; // haplotype 'N' matches every read base (:111-113); rare
     {
         const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
         uint32_t ra[HW + 1], rb[HW + 1];
@@ -113,16 +114,17 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
         }
 #pragma unroll
         for (int k = 0; k < HW; ++k) {
-            ha[k] = __builtin_amdgcn_alignbyte(ra[k + 1], ra[k], sh);
-            hb[k] = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
-        }
-    }
-    // haplotype 'N' matches every read base (:111-113); rare, so the cell loop exists twice
-    unsigned long long na = 0, nb = 0;
+            const uint32_t a = __builtin_amdgcn_alignbyte(ra[k + 1], ra[k], sh);
+            const uint32_t b = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
 #pragma unroll
-    for (int j = 0; j < C; ++j) {
-        na |= (((ha[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N' ? 1ull : 0ull) << j;
-        nb |= (((hb[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)'N' ? 1ull : 0ull) << j;
+            for (int i = 0; i < 4; ++i)
+                if (4 * k + i < C) {
+                    const uint32_t ca = (a >> (8 * i)) & 0xffu, cb = (b >> (8 * i)) & 0xffu;
+                    hq[4 * k + i] = ca | (cb << 16);
+                    na |= (ca == (uint32_t)'N' ? 1ull : 0ull) << (4 * k + i);
+                    nb |= (cb == (uint32_t)'N' ? 1ull : 0ull) << (4 * k + i);
+                }
+        }
     }
 
     const f2 init = f2{g.init32[0], g.init32[1]};
@@ -164,8 +166,7 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
             // pass A, right to left: M and X in place
 #pragma unroll
             for (int j = C - 1; j >= 0; --j) {
-                const uint32_t ca = (ha[j >> 2] >> (8 * (j & 3))) & 0xffu, cb = (hb[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                bool ma = ca == rc, mb = cb == rc;
+                bool ma = (hq[j] & 0xffffu) == rc, mb = (hq[j] >> 16) == rc;
                 if constexpr (HAPN) {
                     ma = ma || ((na >> j) & 1ull);
                     mb = mb || ((nb >> j) & 1ull);
