@@ -56,17 +56,30 @@ int force_cols_per_lane()
     return v;
 }
 
+// kind 0..2 = rows of kPhClassCost over kPhClasses; kind 3 = the packed float kernel's own class table
+struct ClassTable {
+    const int *C;
+    const double *cost;
+    int n;
+};
+ClassTable class_table(int kind)
+{
+    if (kind == 3) return ClassTable{kPhPkClasses, kPhPkClassCost, kPhPkNumClasses};
+    return ClassTable{kPhClasses, kPhClassCost[kind], kPhNumClasses};
+}
+
 void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
 {
+    const ClassTable ct = class_table(precision);
     int best = -1, bestG = 0;
     double best_cost = 0;
-    for (int ci = 0; ci < kPhNumClasses; ++ci) {
-        const int C = kPhClasses[ci];
+    for (int ci = 0; ci < ct.n; ++ci) {
+        const int C = ct.C[ci];
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
         if (C > max_cols_per_lane() && best >= 0) continue;
         if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
-        const double wgt = kPhClassCost[precision][ci];
+        const double wgt = ct.cost[ci];
         if (wgt == 0) continue; // class not built for this arithmetic
         const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G)) * wgt;
         if (best < 0 || cost < best_cost) {
@@ -83,15 +96,16 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t 
 // wave-times, so the tiling of that shape is chosen with that quantisation.
 void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count, int n_simd, uint8_t *cls, uint8_t *G_out)
 {
+    const ClassTable ct = class_table(precision);
     int best = -1, bestG = 0;
     double best_cost = 0;
-    for (int ci = 0; ci < kPhNumClasses; ++ci) {
-        const int C = kPhClasses[ci];
+    for (int ci = 0; ci < ct.n; ++ci) {
+        const int C = ct.C[ci];
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
         if (C > max_cols_per_lane() && best >= 0) continue;
         if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
-        const double wgt = kPhClassCost[precision][ci];
+        const double wgt = ct.cost[ci];
         if (wgt == 0) continue;
         const int64_t per_wave = 64 / G;
         const int64_t waves = (count + per_wave - 1) / per_wave;
@@ -268,6 +282,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         int64_t padded = 0;
     };
     auto make_plan = [&](int kind, int slots, bool rows_f64, PlanOut &po) -> int {
+        const ClassTable ct = class_table(kind);
         std::vector<Plan> gen = gen0;
         std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
         for (Plan &p : gen) {
@@ -280,7 +295,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             }
             p.cls = (uint8_t)(it->second >> 8);
             p.G = (uint8_t)(it->second & 0xff);
-            if (p.cls >= kPhNumClasses) {
+            if (p.cls >= ct.n) {
                 agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", p.read, p.hap, p.H);
                 return AGX_E_LIMIT;
             }
@@ -305,7 +320,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
                 uint8_t c = 255, G = 0;
                 choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count + slots - 1) / slots, 4 * n_cu, &c, &G);
-                if (c < kPhNumClasses)
+                if (c < ct.n)
                     for (Plan &p : gen)
                         if ((p.R << 16 | p.H) == cand) {
                             p.cls = c;
@@ -317,7 +332,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         // adjacent (one LDS table).  `gen` is already (read, haplotype)-ordered: one stable counting pass.
         std::vector<Plan> plan(gen.size());
         {
-            std::vector<uint32_t> cnt((size_t)kPhNumClasses * 64 + 1, 0);
+            std::vector<uint32_t> cnt((size_t)ct.n * 64 + 1, 0);
             auto bucket = [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); };
             for (const Plan &p : gen) ++cnt[bucket(p) + 1];
             for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
@@ -328,7 +343,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         while (i < plan.size()) {
             const int cls = plan[i].cls;
             ClassLaunch cl;
-            cl.C = kPhClasses[cls];
+            cl.C = ct.C[cls];
             cl.first_wave = (uint32_t)po.waves.size();
             while (i < plan.size() && plan[i].cls == cls) {
                 const int G = plan[i].G;

@@ -50,17 +50,24 @@ struct PhWave {
 #define AGX_PH_FOR_EACH_CLASS(X) \
     X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
 // classes of the packed float kernel: six state registers per column, so at most 30 columns
-#define AGX_PH_FOR_EACH_PK_CLASS(X) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30)
+#define AGX_PH_FOR_EACH_PK_CLASS(X) \
+    X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
+    X(24) X(25) X(26) X(27) X(28) X(29) X(30)
+// (every width: with two haplotypes per group and at most 30 columns, odd widths often tile a
+// haplotype over all 64 lanes where the even ones leave lanes idle, e.g. H = 300 = 16 lanes x 19)
+static const int kPhPkClasses[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30};
+static const int kPhPkNumClasses = sizeof(kPhPkClasses) / sizeof(kPhPkClasses[0]);
+// measured for the even widths (profiles/r01_calibration.log), interpolated for the odd ones
+static const double kPhPkClassCost[] = {2.136, 1.914, 1.692, 1.570, 1.449, 1.393, 1.336, 1.292, 1.248, 1.203, 1.159, 1.147, 1.136, 1.133, 1.131, 1.117, 1.103, 1.100, 1.098, 1.079, 1.061, 1.047, 1.033, 1.016, 1.000, 1.107, 1.215};
 static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic
 // (MI355X, tools/calibrate_classes.py, profiles/r01_calibration*.log); 0 = class not built
-// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32, packed f32 FMA.
-static const double kPhClassCost[4][19] = {
+// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.
+static const double kPhClassCost[3][19] = {
     {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.220, 0, 0, 0, 0},
     {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 1.211, 0, 0, 0, 0},
     {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
-    {1.975, 1.544, 1.343, 1.230, 1.176, 1.105, 1.071, 1.067, 1.033, 1.029, 1.004, 1.000, 1.146, 1.142, 0, 0, 0, 0, 0},
 };
 
 // bytes of LDS one table row takes: Qr, Qi, Qd, Qg (+ a separate mismatch prior when it is not
