@@ -147,7 +147,9 @@ struct agx_phmm_batch {
     struct DevPlan {
         DevBuf groups, tabs, waves;
         std::vector<ClassLaunch> launches;
-    } main, rescue;
+    } main, rescue, stripe; // stripe: pairs whose haplotype no class spans, one per wavefront
+    DevBuf stripe_scratch;    // 6 * stripe_rows doubles per workgroup of the striped launch
+    uint32_t stripe_rows = 0, stripe_grid = 0;
     agx_phmm_info info{};
 };
 
@@ -177,15 +179,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         return AGX_E_ARG;
     }
     const bool f64 = precision == AGX_PHMM_F64 || precision == AGX_PHMM_F64_FMA;
-    // the packed float kernel spans at most 64 lanes x 30 columns: one longer haplotype moves the whole
-    // batch to the order-exact float kernel (same tolerance, AGX_PHMM_F32 semantics)
-    if (precision == AGX_PHMM_F32_FMA) {
-        for (uint32_t h = 0; h < d->n_haps && d->hap_off; ++h)
-            if (d->hap_off[h + 1] - d->hap_off[h] > 64u * 30u) {
-                precision = AGX_PHMM_F32;
-                break;
-            }
-    }
     const bool packed = precision == AGX_PHMM_F32_FMA;
     const bool probs = prob != nullptr;
     if (probs && precision != AGX_PHMM_F64) {
@@ -238,6 +231,23 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         }
     }
 
+    // ---- haplotypes wider than 64 lanes x the widest class of this arithmetic go to the striped kernel
+    std::vector<Plan> gen_long;
+    {
+        const ClassTable ct = class_table(precision);
+        uint32_t span = 0;
+        for (int ci = 0; ci < ct.n; ++ci)
+            if (ct.cost[ci] != 0) span = std::max(span, 64u * (uint32_t)ct.C[ci]);
+        size_t keep = 0;
+        for (const Plan &p : gen0) {
+            if (p.H > span)
+                gen_long.push_back(p);
+            else
+                gen0[keep++] = p;
+        }
+        gen0.resize(keep);
+    }
+
     // ---- image: every read and haplotype once, shared by all plans of the batch
     std::vector<uint32_t> img;
     img.resize((64 * 30 + 8) / 4, 0u); // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 30 columns)
@@ -267,7 +277,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         const uint64_t o = d->hap_off[h];
         const uint32_t H = (uint32_t)(d->hap_off[h + 1] - o);
         hap_dw[h] = (uint32_t)img.size();
-        img.resize(img.size() + ((size_t)H + kHapSlack + 3) / 4, 0u);
+        // zero slack: any class tiling, and whole stripes of the striped kernel, read in bounds
+        const size_t stripe = 64u * AGX_PH_STRIPE_COLS;
+        const size_t bytes = std::max((size_t)H + kHapSlack, ((size_t)H + stripe - 1) / stripe * stripe + 8);
+        img.resize(img.size() + (bytes + 3) / 4, 0u);
         memcpy(reinterpret_cast<uint8_t *>(&img[hap_dw[h]]), d->hap_bases + o, H);
     };
 
@@ -429,8 +442,45 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // a packed float batch cannot reuse its records for the double rescue pass: second plan
     if (!rc && packed) rc = make_plan(AGX_PHMM_F64, 1, true, presc);
     if (rc) return rc;
+    // striped plan: one pair per wavefront, every pair its own read table
+    PlanOut pstripe;
+    uint32_t stripe_steps = 0;
+    size_t stripe_lds = 0;
+    for (const Plan &p : gen_long) {
+        put_read(p.read);
+        put_hap(p.hap);
+        PhWave w{};
+        w.first_group = (uint32_t)pstripe.groups1.size();
+        w.first_tab = (uint32_t)pstripe.tabs.size();
+        w.n_groups = 1;
+        w.n_tabs = 1;
+        w.G = 64;
+        w.steps = p.R + 63u;
+        pstripe.tabs.push_back(PhTab{read_dw[p.read], p.R});
+        PhGroup g{};
+        g.hap_dw = hap_dw[p.hap];
+        g.H = p.H;
+        g.R_tab = p.R;
+        g.out = p.out;
+        g.init64 = DBL_MAX / 16 / (double)p.H;
+        g.init32 = FLT_MAX / 16 / (float)p.H;
+        pstripe.groups1.push_back(g);
+        pstripe.waves.push_back(w);
+        stripe_steps = std::max(stripe_steps, w.steps);
+        stripe_lds = std::max(stripe_lds, ph_tab_bytes(true, gatk_prior, w.steps + 63u));
+        const int64_t n_stripes = (p.H + 64 * AGX_PH_STRIPE_COLS - 1) / (64 * AGX_PH_STRIPE_COLS);
+        pstripe.padded += n_stripes * w.steps * 64 * AGX_PH_STRIPE_COLS;
+        if (img.size() > 0xfffffff0ull) {
+            agx_set_error("packed image exceeds 16 GiB; split the batch");
+            return AGX_E_LIMIT;
+        }
+    }
+    if (stripe_lds > 160 * 1024) {
+        agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", stripe_lds);
+        return AGX_E_LIMIT;
+    }
     const double t_plan = now();
-    const int64_t padded = pmain.padded;
+    const int64_t padded = pmain.padded + pstripe.padded;
 
     const double t_pack = now();
     // ---- upload
@@ -452,7 +502,17 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                                     pmain.waves.size() * sizeof(PhWave));
     const bool two_pass = precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA;
     b->info.n_launches = (int32_t)(pmain.launches.size() + (packed ? presc.launches.size() : two_pass ? pmain.launches.size() : 0));
-    b->info.n_waves = (int32_t)pmain.waves.size();
+    b->info.n_waves = (int32_t)(pmain.waves.size() + pstripe.waves.size());
+    if (!pstripe.waves.empty()) {
+        ClassLaunch cl;
+        cl.C = AGX_PH_STRIPE_COLS;
+        cl.n_waves = (uint32_t)pstripe.waves.size();
+        cl.lds = cl.lds_rescue = stripe_lds;
+        b->stripe.launches.push_back(cl);
+        b->info.n_launches += 1;
+        b->stripe_rows = (stripe_steps + 128u + 63u) & ~63u; // a 64-row block may start at the last step, 63 rows ahead
+        b->stripe_grid = std::min<uint32_t>(cl.n_waves, (uint32_t)n_cu * 8u);
+    }
     if (!ctx) { // planning only
         *out = b;
         return AGX_OK;
@@ -467,6 +527,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (!rc && packed) rc = b->rescue.groups.alloc(presc.groups1.size() * sizeof(PhGroup));
     if (!rc && packed) rc = b->rescue.tabs.alloc(presc.tabs.size() * sizeof(PhTab));
     if (!rc && packed) rc = b->rescue.waves.alloc(presc.waves.size() * sizeof(PhWave));
+    if (!rc && !pstripe.waves.empty()) {
+        rc = b->stripe.groups.alloc(pstripe.groups1.size() * sizeof(PhGroup));
+        if (!rc) rc = b->stripe.tabs.alloc(pstripe.tabs.size() * sizeof(PhTab));
+        if (!rc) rc = b->stripe.waves.alloc(pstripe.waves.size() * sizeof(PhWave));
+        if (!rc) rc = b->stripe_scratch.alloc((size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
+    }
     if (!rc) rc = b->sums.alloc(((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->lut.alloc(2 * (sizeof lut_d + sizeof lut_f)); // [lut_d][lut_f][mis_d][mis_f]
     if (!rc) rc = b->counter.alloc(sizeof(unsigned long long));
@@ -486,6 +552,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         up(b->rescue.groups, presc.groups1.data(), presc.groups1.size() * sizeof(PhGroup));
         up(b->rescue.tabs, presc.tabs.data(), presc.tabs.size() * sizeof(PhTab));
         up(b->rescue.waves, presc.waves.data(), presc.waves.size() * sizeof(PhWave));
+    }
+    if (!pstripe.waves.empty()) {
+        up(b->stripe.groups, pstripe.groups1.data(), pstripe.groups1.size() * sizeof(PhGroup));
+        up(b->stripe.tabs, pstripe.tabs.data(), pstripe.tabs.size() * sizeof(PhTab));
+        up(b->stripe.waves, pstripe.waves.data(), pstripe.waves.size() * sizeof(PhWave));
+        if (e == hipSuccess) e = hipMemset(b->stripe_scratch.p, 0, b->stripe_scratch.bytes);
     }
     up(b->lut, lut_d, sizeof lut_d);
     if (e == hipSuccess) e = hipMemcpy((char *)b->lut.p + sizeof lut_d, lut_f, sizeof lut_f, hipMemcpyHostToDevice);
@@ -516,7 +588,8 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     b->img.release();
-    for (agx_phmm_batch::DevPlan *pl : {&b->main, &b->rescue}) {
+    b->stripe_scratch.release();
+    for (agx_phmm_batch::DevPlan *pl : {&b->main, &b->rescue, &b->stripe}) {
         pl->groups.release();
         pl->tabs.release();
         pl->waves.release();
@@ -567,10 +640,24 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     };
     // the counter reset above is ordered before the fork; different classes run side by side
     {
-        FanOut fan(b->ctx, (int)b->main.launches.size());
+        FanOut fan(b->ctx, (int)(b->main.launches.size() + b->stripe.launches.size()));
         rc = fan.begin();
         if (rc) return rc;
         int k = 0;
+        for (const ClassLaunch &cl : b->stripe.launches) { // longest-running waves first
+            const bool fma = b->precision == AGX_PHMM_F64_FMA || b->precision == AGX_PHMM_F32_FMA;
+            const int mode = b->probs ? 4 : fma ? 1 : 0;
+            // a float batch's long pairs are computed in double: stored negated like its rescued pairs
+            const int r = agx_phmm_stripe_launch(mode, (const uint32_t *)b->img.p, (const PhGroup *)b->stripe.groups.p,
+                                                 (const PhTab *)b->stripe.tabs.p, (const PhWave *)b->stripe.waves.p, cl.n_waves,
+                                                 b->stripe_grid, lut_d, mis_for_d, (double *)b->sums.p,
+                                                 (double *)b->stripe_scratch.p, b->stripe_rows, f32_family ? 1 : 0, cl.lds,
+                                                 fan.stream(k++));
+            if (r) {
+                agx_set_error("phmm_fill_striped launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return AGX_E_HIP;
+            }
+        }
         for (const ClassLaunch &cl : b->main.launches) {
             hipStream_t st = fan.stream(k++);
             if (b->packed) {

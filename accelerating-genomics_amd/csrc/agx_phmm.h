@@ -84,6 +84,13 @@ __host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, ui
 int agx_phmm_pk_launch_class(int cols_per_lane, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              size_t lds_bytes, hipStream_t s);
+// Haplotypes no class can span (more than 64 lanes x the widest class of the batch's arithmetic) run
+// one pair per wavefront in stripes of 64 x AGX_PH_STRIPE_COLS columns, always in double (mode 0, 1
+// or 4).  grid workgroups walk the n_waves pairs; scratch holds 6 * scratch_rows doubles per workgroup.
+#define AGX_PH_STRIPE_COLS 30
+int agx_phmm_stripe_launch(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
+                           uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
                           const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                           double rescue_below,

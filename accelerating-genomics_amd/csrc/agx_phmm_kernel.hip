@@ -166,7 +166,12 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
         Y[j] = init;
     }
     T pM = 0, pX = 0, pY = init; // what arrived from the left one step ago = diagonal neighbour
-    T acc_prev = 0, result = 0;
+    // double: the sum runs down the lanes in column order (reference order).  float: every lane sums
+    // its columns of the last row in double and the lanes are combined after the loop -- a float
+    // running sum over thousands of columns would lose the 1e-6 the mode promises.
+    constexpr bool CHAIN = sizeof(T) == 8;
+    T acc_prev = 0;
+    double result = 0, part = 0;
     const int steps = (int)w.steps;
     const int col0 = gl * C;
 
@@ -182,7 +187,8 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
             const T gm = 1 - q_g;
 
             T lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
-            T acc = shr1(acc_prev);
+            T acc = 0;
+            if constexpr (CHAIN) acc = shr1(acc_prev);
             if (start) { // column 0 of rows >= 1 (:168-178)
                 lM = 0;
                 lX = 0;
@@ -219,12 +225,18 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
                 Y[j] = y;
             }
             if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+                if constexpr (CHAIN) {
 #pragma unroll
-                for (int j = 0; j < C; ++j)
-                    if (col0 + j < H) acc += (M[j] + X[j]);
-                if (gl == G - 1) result = acc;
+                    for (int j = 0; j < C; ++j)
+                        if (col0 + j < H) acc += (M[j] + X[j]);
+                    if (gl == G - 1) result = acc;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j)
+                        if (col0 + j < H) part += (double)(M[j] + X[j]);
+                }
             }
-            acc_prev = acc;
+            if constexpr (CHAIN) acc_prev = acc;
         }
     };
     if (__any(nmask != 0))
@@ -232,6 +244,13 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
     else
         fill(std::false_type{});
 
+    if constexpr (!CHAIN) { // inclusive scan over the group's lanes: its last lane ends with the total
+        for (int dlt = 1; dlt < G; dlt <<= 1) {
+            const double v = __shfl_up(part, dlt);
+            if (gl >= dlt) part += v;
+        }
+        result = part;
+    }
     if (wanted && gl == G - 1) {
         // the rescue pass stores its (double-scaled) sum negated so the host can tell the scalings apart
         sums[g.out] = RESCUE ? -(double)result : (double)result;

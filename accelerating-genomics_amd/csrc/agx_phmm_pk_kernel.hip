@@ -136,7 +136,9 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
         Y[j] = init;
     }
     f2 pM = splat(0.f), pX = splat(0.f), pY = init;
-    f2 acc_prev = splat(0.f), result = splat(0.f);
+    // every lane sums its columns of the last row in double; the lanes are combined after the loop
+    // (a float running sum over thousands of columns would lose the 1e-6 the mode promises)
+    double part_a = 0, part_b = 0;
     const int steps = (int)w.steps;
     const int col0 = gl * C;
 
@@ -152,12 +154,10 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
             const f2 qi = splat(q_i), qd = splat(q_d), qg = splat(q_g);
 
             f2 lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
-            f2 acc = shr1(acc_prev);
             if (start) { // column 0 of rows >= 1 (:168-178)
                 lM = splat(0.f);
                 lX = splat(0.f);
                 lY = splat(0.f);
-                acc = splat(0.f);
             }
             const f2 dM0 = pM, dX0 = pX, dY0 = pY;
             pM = lM;
@@ -192,12 +192,10 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
             if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
-                    if (col0 + j < HA) acc.x += (M[j].x + X[j].x);
-                    if (col0 + j < HB) acc.y += (M[j].y + X[j].y);
+                    if (col0 + j < HA) part_a += (double)(M[j].x + X[j].x);
+                    if (col0 + j < HB) part_b += (double)(M[j].y + X[j].y);
                 }
-                if (gl == G - 1) result = acc;
             }
-            acc_prev = acc;
         }
     };
     if (__any((na | nb) != 0))
@@ -205,9 +203,16 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
     else
         fill(std::false_type{});
 
+    for (int dlt = 1; dlt < G; dlt <<= 1) { // inclusive scan over the group's lanes
+        const double va = __shfl_up(part_a, dlt), vb = __shfl_up(part_b, dlt);
+        if (gl >= dlt) {
+            part_a += va;
+            part_b += vb;
+        }
+    }
     if (active && gl == G - 1) {
-        sums[g.out[0]] = (double)result.x;
-        sums[g.out[1]] = (double)result.y; // a group without a second haplotype points this at the spare slot
+        sums[g.out[0]] = part_a;
+        sums[g.out[1]] = part_b; // a group without a second haplotype points this at the spare slot
     }
 }
 

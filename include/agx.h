@@ -47,9 +47,11 @@ extern "C" {
  * with a longer one runs the int32 kernel with its wide classes. */
 #define AGX_SW_MAX_COLS_PER_LANE 160
 #define AGX_SW_MAX_SHORT_LEN (64 * AGX_SW_MAX_COLS_PER_LANE)
-/* PairHMM: haplotype across lanes (64 x AGX_PHMM_MAX_COLS_PER_LANE), read streams. */
+/* PairHMM: haplotype across lanes, read streams.  Up to 64 lanes x AGX_PHMM_MAX_COLS_PER_LANE
+ * columns a pair is filled in one pass; longer haplotypes (the reference's line buffer allows
+ * 5000, antidiagsPairHMM.c:8,353) are filled in stripes of 1920 columns by one wavefront. */
 #define AGX_PHMM_MAX_COLS_PER_LANE 32
-#define AGX_PHMM_MAX_HAP_LEN (64 * AGX_PHMM_MAX_COLS_PER_LANE)
+#define AGX_PHMM_MAX_HAP_LEN 16384
 #define AGX_PHMM_MAX_READ_LEN 4096
 
 /* ------------------------------------------------------------------ runtime */

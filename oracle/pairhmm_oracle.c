@@ -168,10 +168,12 @@ double oracle_pairhmm_sum_f64_antidiag(const unsigned char *R, int rl, const uns
 /*
  * fp32 restatement for BASELINE config 3.  The reference has no fp32 code
  * (SURVEY.md Q12); this follows the same expression order in float with the
- * initial constant FLT_MAX/16 and the final log10 taken in double.
+ * initial constant FLT_MAX/16; the last row is summed in double (a float
+ * running sum over thousands of columns alone would exceed 1e-6) and the final
+ * log10 is taken in double.
  * Its tolerance vs the fp64 oracle is what tests assert (1e-6 relative).
  */
-float oracle_pairhmm_sum_f32(const unsigned char *R, int rl, const unsigned char *H, int hl,
+double oracle_pairhmm_sum_f32(const unsigned char *R, int rl, const unsigned char *H, int hl,
                              const double *Qr, const double *Qi, const double *Qd, const double *Qg)
 {
     size_t w = (size_t)hl + 1;
@@ -193,8 +195,8 @@ float oracle_pairhmm_sum_f32(const unsigned char *R, int rl, const unsigned char
         t = Xp; Xp = Xc; Xc = t;
         t = Yp; Yp = Yc; Yc = t;
     }
-    float l = 0;
-    for (int j = 1; j <= hl; j++) l += (Mp[j] + Xp[j]);
+    double l = 0;
+    for (int j = 1; j <= hl; j++) l += (double)(Mp[j] + Xp[j]);
     free(buf);
     return l;
 }

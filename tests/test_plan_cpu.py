@@ -69,5 +69,9 @@ def test_phmm_plans(prec):
         p.launch()
     p.close()
     with pytest.raises(agx.AgxError) as e:
-        agx.PhmmBatchDev(None, synth.phmm_regions(1, 1, 1, 10, 2100, seed=1), prec)
+        agx.PhmmBatchDev(None, synth.phmm_regions(1, 1, 1, 10, 16385, seed=1), prec)
     assert e.value.code == agx.E_LIMIT
+    # a haplotype no class spans is planned for the striped kernel: one more launch, one wave per pair
+    q = agx.PhmmBatchDev(None, synth.phmm_regions(1, 2, 3, 10, 5000, seed=1), prec)
+    assert q.info().n_launches == 1 and q.info().n_waves == 6
+    q.close()
