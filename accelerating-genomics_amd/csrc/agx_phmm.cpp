@@ -56,6 +56,8 @@ int force_cols_per_lane()
     return v;
 }
 
+constexpr int stripe_cols() { return AGX_PH_STRIPE_COLS; }
+
 // kind 0..2 = rows of kPhClassCost over kPhClasses; kind 3 = the packed float kernel's own class table
 struct ClassTable {
     const int *C;
@@ -278,7 +280,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         const uint32_t H = (uint32_t)(d->hap_off[h + 1] - o);
         hap_dw[h] = (uint32_t)img.size();
         // zero slack: any class tiling, and whole stripes of the striped kernel, read in bounds
-        const size_t stripe = 64u * AGX_PH_STRIPE_COLS;
+        const size_t stripe = 64u * (size_t)stripe_cols();
         const size_t bytes = std::max((size_t)H + kHapSlack, ((size_t)H + stripe - 1) / stripe * stripe + 8);
         img.resize(img.size() + (bytes + 3) / 4, 0u);
         memcpy(reinterpret_cast<uint8_t *>(&img[hap_dw[h]]), d->hap_bases + o, H);
@@ -468,8 +470,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         pstripe.waves.push_back(w);
         stripe_steps = std::max(stripe_steps, w.steps);
         stripe_lds = std::max(stripe_lds, ph_tab_bytes(true, gatk_prior, w.steps + 63u));
-        const int64_t n_stripes = (p.H + 64 * AGX_PH_STRIPE_COLS - 1) / (64 * AGX_PH_STRIPE_COLS);
-        pstripe.padded += n_stripes * w.steps * 64 * AGX_PH_STRIPE_COLS;
+        const int64_t n_stripes = (p.H + 64 * stripe_cols() - 1) / (64 * stripe_cols());
+        pstripe.padded += n_stripes * w.steps * 64 * stripe_cols();
         if (img.size() > 0xfffffff0ull) {
             agx_set_error("packed image exceeds 16 GiB; split the batch");
             return AGX_E_LIMIT;
@@ -505,7 +507,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->info.n_waves = (int32_t)(pmain.waves.size() + pstripe.waves.size());
     if (!pstripe.waves.empty()) {
         ClassLaunch cl;
-        cl.C = AGX_PH_STRIPE_COLS;
+        cl.C = stripe_cols();
         cl.n_waves = (uint32_t)pstripe.waves.size();
         cl.lds = cl.lds_rescue = stripe_lds;
         b->stripe.launches.push_back(cl);
@@ -648,7 +650,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
             const bool fma = b->precision == AGX_PHMM_F64_FMA || b->precision == AGX_PHMM_F32_FMA;
             const int mode = b->probs ? 4 : fma ? 1 : 0;
             // a float batch's long pairs are computed in double: stored negated like its rescued pairs
-            const int r = agx_phmm_stripe_launch(mode, (const uint32_t *)b->img.p, (const PhGroup *)b->stripe.groups.p,
+            const int r = agx_phmm_stripe_launch(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->stripe.groups.p,
                                                  (const PhTab *)b->stripe.tabs.p, (const PhWave *)b->stripe.waves.p, cl.n_waves,
                                                  b->stripe_grid, lut_d, mis_for_d, (double *)b->sums.p,
                                                  (double *)b->stripe_scratch.p, b->stripe_rows, f32_family ? 1 : 0, cl.lds,

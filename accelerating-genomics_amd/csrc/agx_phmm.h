@@ -85,10 +85,13 @@ int agx_phmm_pk_launch_class(int cols_per_lane, const uint32_t *img, const PhGro
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              size_t lds_bytes, hipStream_t s);
 // Haplotypes no class can span (more than 64 lanes x the widest class of the batch's arithmetic) run
-// one pair per wavefront in stripes of 64 x AGX_PH_STRIPE_COLS columns, always in double (mode 0, 1
+// one pair per wavefront in stripes of 64 x AGX_PH_STRIPE_COLS = 1536 columns, always in double (mode 0, 1
 // or 4).  grid workgroups walk the n_waves pairs; scratch holds 6 * scratch_rows doubles per workgroup.
-#define AGX_PH_STRIPE_COLS 30
-int agx_phmm_stripe_launch(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+// 24 columns: the widest tiling that keeps two waves per SIMD (<= 256 VGPRs) without spills in the
+// cell loop; measured against 26/28/30 in profiles/r01_calibration.log ("striped kernel").
+#define AGX_PH_STRIPE_COLS 24
+#define AGX_PH_FOR_EACH_STRIPE_CLASS(X) X(24)
+int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
                            uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,

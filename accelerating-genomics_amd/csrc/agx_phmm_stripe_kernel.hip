@@ -5,7 +5,9 @@
 //
 // What differs from phmm_fill:
 //   * One pair per wavefront (G = 64), double arithmetic only; a workgroup walks the plan's pairs
-//     grid-stride so that its boundary scratch is reused.
+//     grid-stride so that its boundary scratch is reused.  Two waves per SIMD are requested
+//     (amdgpu_waves_per_eu): the stripe bookkeeping would otherwise push the kernel past 256 VGPRs
+//     and halve the occupancy, which costs more than the few spills outside the cell loop.
 //   * Between stripes the last column of stripe s (M, X, Y of every read row) is the column-0
 //     input of stripe s+1.  Lane 63 stores its three values every step to a per-workgroup
 //     scratch in HBM (24 B/step, indexed by the step that produced them); the next stripe loads
@@ -26,11 +28,11 @@ namespace {
 using namespace agx_ph;
 
 template <int C, bool FMA, bool PROBS>
-__global__ void __launch_bounds__(64) phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
-                                                        const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
-                                                        uint32_t n_waves, const double *__restrict__ lut,
-                                                        const double *__restrict__ lut_mis, double *__restrict__ sums,
-                                                        double *__restrict__ scratch, uint32_t scratch_rows, int negate)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
+                  const PhWave *__restrict__ waves, uint32_t n_waves, const double *__restrict__ lut,
+                  const double *__restrict__ lut_mis, double *__restrict__ sums, double *__restrict__ scratch,
+                  uint32_t scratch_rows, int negate)
 {
     constexpr int G = 64;
     constexpr int HW = (C + 3) / 4;
@@ -187,19 +189,32 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-} // namespace
-
-int agx_phmm_stripe_launch(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
-                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
-                           uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s)
+template <int C>
+int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
+                uint32_t grid, const double *l, const double *lm, double *sums, double *scratch, uint32_t scratch_rows,
+                int negate, size_t lds_bytes, hipStream_t s)
 {
-    if (n_waves == 0) return 0;
-    constexpr int C = AGX_PH_STRIPE_COLS;
-    const double *l = (const double *)lut, *lm = (const double *)lut_mis;
     switch (mode) {
     case 0: return launch<C, false, false>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
     case 1: return launch<C, true, false>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
     case 4: return launch<C, false, true>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
     default: return -2;
     }
+}
+
+} // namespace
+
+int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
+                           uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    const double *l = (const double *)lut, *lm = (const double *)lut_mis;
+#define AGX_PH_CASE(CC) \
+    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
+    switch (cols_per_lane) {
+        AGX_PH_FOR_EACH_STRIPE_CLASS(AGX_PH_CASE)
+    default: return -2;
+    }
+#undef AGX_PH_CASE
 }

@@ -49,7 +49,7 @@ extern "C" {
 #define AGX_SW_MAX_SHORT_LEN (64 * AGX_SW_MAX_COLS_PER_LANE)
 /* PairHMM: haplotype across lanes, read streams.  Up to 64 lanes x AGX_PHMM_MAX_COLS_PER_LANE
  * columns a pair is filled in one pass; longer haplotypes (the reference's line buffer allows
- * 5000, antidiagsPairHMM.c:8,353) are filled in stripes of 1920 columns by one wavefront. */
+ * 5000, antidiagsPairHMM.c:8,353) are filled in stripes of 1536 columns by one wavefront. */
 #define AGX_PHMM_MAX_COLS_PER_LANE 32
 #define AGX_PHMM_MAX_HAP_LEN 16384
 #define AGX_PHMM_MAX_READ_LEN 4096

@@ -103,6 +103,18 @@ def main():
     far = synth.phmm_regions(1, 4, 2, 100, 300, seed=14)
     far.read_bases[:] = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(15).integers(0, 4, far.read_bases.size)]
     synth.write_phmm_file(os.path.join(HERE, "phmm_far.in"), far)
+    # haplotypes up to the reference's line buffer (5001 bytes, antidiagsPairHMM.c:8,353): the product's
+    # striped kernel; phmm_matrix_ref and phmm_antidiag_ref are run on it like on the others
+    lng = synth.phmm_regions(1, 3, 3, 250, 4999, seed=16, jitter=0)
+    regs = []
+    rng = np.random.default_rng(17)
+    reads = [tuple(x[int(lng.roff[r]):int(lng.roff[r + 1])].tobytes() for x in (lng.read_bases, lng.q_base, lng.q_ins, lng.q_del, lng.q_gcp))
+             for r in range(3)]
+    full = [lng.hap_bases[int(lng.hoff[h]):int(lng.hoff[h + 1])].tobytes() for h in range(3)]
+    regs.append((reads, [full[0], full[1][1200:3800], full[2][:2000]]))
+    regs.append((reads[:1], [full[2][100:2149]]))
+    synth.write_phmm_file(os.path.join(HERE, "phmm_long.in"), synth.phmm_from_regions(regs))
+    run_phmm("phmm_long")
     run_phmm("phmm_test")
     assert open(os.path.join(HERE, "phmm_test.f.out"), "rb").read() == open(os.path.join(HERE, "phmm_test.out"), "rb").read()
     run_phmm("phmm_10s", antidiag=False)  # antidiag on 10s.in leaks 1.5 GB (Q9); equality was measured in SURVEY.md

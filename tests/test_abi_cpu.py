@@ -86,7 +86,7 @@ def test_sw_text_reader_errors(tmp_path):
     assert "file is empty" in str(e.value)
 
 
-@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"])
+@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far", "phmm_long"])
 def test_phmm_text_reader_matches_python_mirror(golden_dir, name):
     path = os.path.join(golden_dir, name + ".in")
     got, seen, trunc = agx.read_phmm_text(path)

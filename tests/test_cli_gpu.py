@@ -42,7 +42,7 @@ def test_sw_cli_usage_and_errors(tmp_path):
     assert r.returncode == 1 and r.stdout == b"file is empty"
 
 
-@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"])
+@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far", "phmm_long"])
 def test_phmm_cli_output_file_and_stdout_identical(golden_dir, tmp_path, name):
     outp = tmp_path / "o.out"
     r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), os.path.join(golden_dir, name + ".in"), str(outp)],

@@ -7,7 +7,7 @@ import pytest
 
 import accelerating_genomics_amd.synth as synth
 
-NAMES = ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"]
+NAMES = ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far", "phmm_long"]
 
 
 def g17(golden_dir, name):

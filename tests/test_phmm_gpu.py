@@ -13,7 +13,7 @@ import accelerating_genomics_amd.synth as synth
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far"]
+NAMES = ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far", "phmm_long"]
 
 
 @pytest.fixture(scope="module")
@@ -87,8 +87,8 @@ def test_f32_fill_matches_f32_oracle_where_not_rescued(ctx, oracle, golden_dir):
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 70), (70, 1), (3, 200), (64, 64), (65, 63), (130, 40), (250, 500),
                                    (400, 1000), (1000, 130), (17, 2048),
-                                   # haplotypes no class spans: striped kernel (1920 columns per stripe)
-                                   (100, 2100), (40, 3841), (250, 5000), (1000, 5000), (5, 9000)])
+                                   # haplotypes no class spans: striped kernel (1536 columns per stripe)
+                                   (100, 2100), (40, 3073), (250, 5000), (1000, 5000), (5, 9000)])
 def test_shapes_vs_oracle(ctx, oracle, shape):
     R, H = shape
     b = synth.phmm_regions(2, 3, 3, R, H, seed=R * 7 + H, jitter=min(R, H) // 3)
@@ -109,7 +109,7 @@ def test_striped_and_single_pass_pairs_in_one_batch(ctx, oracle):
     """Haplotypes on either side of every span (1920 packed, 2048 f64, 2560 f32) in one region; the
     reference's line buffer allows haplotypes up to 5000 (antidiagsPairHMM.c:8,353)."""
     rng = np.random.default_rng(5)
-    hap_lens = [300, 1920, 1921, 2048, 2049, 2560, 2561, 3840, 4999]
+    hap_lens = [300, 1920, 1921, 2048, 2049, 2560, 2561, 3072, 3073, 4608, 4999]
     haps = [synth._ACGT[rng.integers(0, 4, size=n)].tobytes() for n in hap_lens]
     reads = []
     for R in (1, 63, 64, 65, 129, 300):

@@ -21,3 +21,8 @@ for (nr,reads,haps,R,H,name,reps) in ((64,64,16,100,300,"C3",20),(64,32,16,250,5
     for prec,pn in ((agx.PHMM_F32_FMA,"f32fma"),(agx.PHMM_F32,"f32"),(agx.PHMM_F64,"f64"),(agx.PHMM_F64_FMA,"fma")):
         dev = ctx.phmm_batch(p, prec); info = dev.info(); ms = timeit(dev, reps)
         print("PHMM %s %s: %.4f ms %.2f Mpairs/s eff %.3f waves %d" % (name, pn, ms, p.n_pairs/ms/1e3, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()
+# haplotypes beyond one wave's span: striped kernel, one pair per wavefront
+p = synth.phmm_regions(16, 32, 16, 250, 5000, seed=6)
+for prec, pn in ((agx.PHMM_F64, "f64"), (agx.PHMM_F64_FMA, "fma")):
+    dev = ctx.phmm_batch(p, prec); info = dev.info(); ms = timeit(dev, 2)
+    print("PHMM long 250x5000 %s: %.3f ms %.3f Mpairs/s %.1f GCUPS eff %.3f waves %d" % (pn, ms, p.n_pairs/ms/1e3, info.cells/ms/1e6, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()
