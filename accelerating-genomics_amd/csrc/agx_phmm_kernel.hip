@@ -232,8 +232,12 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
                     if (gl == G - 1) result = acc;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < C; ++j)
+                    for (int j = 0; j < C; ++j) {
                         if (col0 + j < H) part += (double)(M[j] + X[j]);
+                        // keep the conversions next to their adds: hoisted together they would hold
+                        // 2C extra registers live and cost a wave of occupancy
+                        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             if constexpr (CHAIN) acc_prev = acc;

@@ -194,6 +194,8 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
                 for (int j = 0; j < C; ++j) {
                     if (col0 + j < HA) part_a += (double)(M[j].x + X[j].x);
                     if (col0 + j < HB) part_b += (double)(M[j].y + X[j].y);
+                    // keep the conversions next to their adds (register pressure)
+                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
