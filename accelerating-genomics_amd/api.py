@@ -19,7 +19,7 @@ PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
 SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
     "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_timer_start", "agx_ctx_timer_stop",
-    "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
+    "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi",
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
     "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_pairHMM",
@@ -40,6 +40,28 @@ class SwInfo(C.Structure):
 
 class SwScoring(C.Structure):
     _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
+
+
+class SwMatrix(C.Structure):
+    """agx_sw_matrix: substitution matrix over up to 32 symbols (include/agx.h)."""
+    _fields_ = [("n_symbols", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32), ("code", C.c_uint8 * 256),
+                ("score", (C.c_int8 * 32) * 32)]
+
+    @classmethod
+    def build(cls, alphabet: bytes, scores, gap_open: int, gap_extend: int, case_insensitive: bool = True):
+        """alphabet: one byte per symbol; scores: n x n integers in alphabet order."""
+        m = cls()
+        m.n_symbols, m.gap_open, m.gap_extend = len(alphabet), gap_open, gap_extend
+        for k in range(256):
+            m.code[k] = 0xff
+        for i, ch in enumerate(alphabet):
+            m.code[ch] = i
+            if case_insensitive and bytes([ch]).isalpha():
+                m.code[ord(bytes([ch]).swapcase())] = i
+        for a in range(len(alphabet)):
+            for c in range(len(alphabet)):
+                m.score[a][c] = int(scores[a][c])
+        return m
 
 
 class PhmmDesc(C.Structure):
@@ -92,6 +114,8 @@ def lib():
         l.agx_sw_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.POINTER(C.c_void_p)]
         l.agx_sw_batch_create_scored.argtypes = [C.c_void_p, C.POINTER(SwScoring), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int64, C.POINTER(C.c_void_p)]
+        l.agx_sw_batch_create_matrix.argtypes = [C.c_void_p, C.POINTER(SwMatrix), C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_int64, C.POINTER(C.c_void_p)]
         l.agx_sw_batch_launch.argtypes = [C.c_void_p]
         l.agx_sw_batch_scores.argtypes = [C.c_void_p, C.c_void_p]
@@ -173,8 +197,8 @@ class Context:
         return ms.value
 
     # ---- Smith-Waterman
-    def sw_batch(self, b, scoring=None) -> "SwBatch":
-        return SwBatch(self, b, scoring)
+    def sw_batch(self, b, scoring=None, matrix=None) -> "SwBatch":
+        return SwBatch(self, b, scoring, matrix)
 
     def sw_score(self, b) -> np.ndarray:
         """b: synth.SWBatch (bases/off/len) -> int32 scores, one-shot."""
@@ -196,11 +220,16 @@ class Context:
 class SwBatch:
     """agx_sw_batch: a scheduled batch resident in HBM (ctx=None: planned on the host only)."""
 
-    def __init__(self, ctx, b, scoring=None):
-        """scoring: None (the reference's +1/-1/-3/-1) or (match, mismatch, gap_open, gap_extend)."""
+    def __init__(self, ctx, b, scoring=None, matrix=None):
+        """scoring: None (the reference's +1/-1/-3/-1) or (match, mismatch, gap_open, gap_extend);
+        matrix: an SwMatrix instead."""
         self.ctx = ctx
         self.n_pairs = b.n_pairs
         self._h = C.c_void_p()
+        if matrix is not None:
+            _check(lib().agx_sw_batch_create_matrix(ctx._h if ctx else None, C.byref(matrix), _ptr(b.bases), _ptr(b.off),
+                                                    _ptr(b.len), b.n_pairs, C.byref(self._h)))
+            return
         sc = C.byref(SwScoring(*scoring)) if scoring is not None else None
         _check(lib().agx_sw_batch_create_scored(ctx._h if ctx else None, sc, _ptr(b.bases), _ptr(b.off), _ptr(b.len),
                                                 b.n_pairs, C.byref(self._h)))

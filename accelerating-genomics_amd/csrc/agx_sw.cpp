@@ -128,9 +128,16 @@ struct agx_sw_batch {
     SwParams prm{};
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
+    DevBuf table; // substitution-matrix mode: kSwMatDim^2 int16 entries
+    bool matrix = false;
     std::vector<ClassLaunch> launches;
     agx_sw_info info{};
 };
+
+namespace {
+int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matrix *matrix, const uint8_t *bases,
+                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out);
+}
 
 extern "C" {
 
@@ -142,6 +149,7 @@ void agx_sw_batch_destroy(agx_sw_batch *b)
     b->groups.release();
     b->waves.release();
     b->scores.release();
+    b->table.release();
     delete b;
 }
 
@@ -153,6 +161,26 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
 
 int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, const uint8_t *bases, const uint64_t *off,
                                const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
+{
+    return create_batch(ctx, scoring, nullptr, bases, off, len, n_pairs, out);
+}
+
+int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const uint8_t *bases, const uint64_t *off,
+                               const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
+{
+    if (!matrix) {
+        agx_set_error("agx_sw_batch_create_matrix: matrix is NULL");
+        return AGX_E_ARG;
+    }
+    return create_batch(ctx, nullptr, matrix, bases, off, len, n_pairs, out);
+}
+
+} // extern "C"
+
+namespace {
+
+int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matrix *matrix, const uint8_t *bases,
+                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
 {
     if (!out) {
         agx_set_error("agx_sw_batch_create: out is NULL");
@@ -174,7 +202,36 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
 
     // ---- scoring -> kernel constants
     const agx_sw_scoring ref_scoring = AGX_SW_SCORING_REFERENCE;
-    const agx_sw_scoring sc = scoring ? *scoring : ref_scoring;
+    agx_sw_scoring sc = scoring ? *scoring : ref_scoring;
+    std::vector<int16_t> table; // matrix mode: [kSwMatDim][kSwMatDim], row/column 0 = padding
+    if (matrix) {
+        const int n = matrix->n_symbols;
+        if (n < 1 || n > AGX_SW_MATRIX_MAX_SYMBOLS) {
+            agx_set_error("substitution matrix: %d symbols, supported 1..%d", n, AGX_SW_MATRIX_MAX_SYMBOLS);
+            return AGX_E_ARG;
+        }
+        int lo = 0;
+        for (int a = 0; a < n; ++a)
+            for (int c = 0; c < n; ++c) {
+                if (matrix->score[a][c] != matrix->score[c][a]) {
+                    agx_set_error("substitution matrix is not symmetric at (%d, %d)", a, c);
+                    return AGX_E_ARG;
+                }
+                lo = std::min(lo, (int)matrix->score[a][c]);
+            }
+        for (int k = 0; k < 256; ++k)
+            if (matrix->code[k] != 0xff && matrix->code[k] >= n) {
+                agx_set_error("substitution matrix: code[%d] = %d is not a symbol number below %d", k, matrix->code[k], n);
+                return AGX_E_ARG;
+            }
+        // the generic range check below sees a match/mismatch pair that always passes
+        sc = agx_sw_scoring{1, 0, matrix->gap_open, matrix->gap_extend};
+        const int gf = matrix->gap_open + matrix->gap_extend;
+        // padding cells score the matrix minimum (<= 0): they cannot raise a local-alignment maximum
+        table.assign((size_t)kSwMatDim * kSwMatDim, (int16_t)(lo - gf));
+        for (int a = 0; a < n; ++a)
+            for (int c = 0; c < n; ++c) table[(size_t)(a + 1) * kSwMatDim + (c + 1)] = (int16_t)(matrix->score[a][c] - gf);
+    }
     // mismatch <= 0: padding relies on never-matching symbols not raising a score
     if (sc.match < 1 || sc.match > 12 || sc.mismatch > 0 || sc.mismatch < sc.match - 128 || sc.gap_open > 0 ||
         sc.gap_open < -1000 || sc.gap_extend > 0 || sc.gap_extend < -1000) {
@@ -196,14 +253,14 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     prm.delta2 = twice(prm.delta);
     // the packed int16 kernel covers shorter sides up to 64 x 40 columns; one longer pair moves the
     // whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160)
-    bool packed = use_packed_kernel();
+    bool packed = use_packed_kernel() && !matrix; // the matrix lookup exists in the int32 kernel only
     if (packed)
         for (int64_t p = 0; p < n_pairs; ++p)
             if (std::min(len[2 * p], len[2 * p + 1]) > (uint32_t)kSwPackedMaxShort) {
                 packed = false;
                 break;
             }
-    const uint32_t max_short = AGX_SW_MAX_SHORT_LEN;
+    const uint32_t max_short = matrix ? (uint32_t)kSwPackedMaxShort : AGX_SW_MAX_SHORT_LEN; // no wide classes in matrix mode
 
     const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -238,11 +295,20 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
             const uint32_t lx = second_short ? lb : la, ly = second_short ? la : lb;
             int rc = AGX_OK;
             Tiling tl{-1, 0};
+            bool bad_symbol;
+            if (matrix) { // any byte outside the alphabet maps to 0xff
+                const uint8_t *q = bases + off[2 * p], *r = bases + off[2 * p + 1];
+                uint8_t bad = 0;
+                for (uint32_t k = 0; k < la; ++k) bad |= (uint8_t)(matrix->code[q[k]] == 0xff);
+                for (uint32_t k = 0; k < lb; ++k) bad |= (uint8_t)(matrix->code[r[k]] == 0xff);
+                bad_symbol = bad != 0;
+            } else
+                bad_symbol = memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb);
             if (lx > max_short || ly > 0xffffu) rc = AGX_E_LIMIT;
-            else if (memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb)) rc = AGX_E_SYMBOL;
+            else if (bad_symbol) rc = AGX_E_SYMBOL;
             else {
                 tl = choose_tiling(packed, (int)lx, (int)ly);
-                if (tl.cls < 0) rc = AGX_E_LIMIT;
+                if (tl.cls < 0 || (matrix && kSwClasses[tl.cls] > 40)) rc = AGX_E_LIMIT; // no wide classes in matrix mode
             }
             if (rc != AGX_OK) {
                 if (me.rc == AGX_OK) {
@@ -263,7 +329,9 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     for (const Worker &w : wk)
         if (w.rc != AGX_OK) {
             const int64_t p = w.bad_pair;
-            if (w.rc == AGX_E_SYMBOL)
+            if (w.rc == AGX_E_SYMBOL && matrix)
+                agx_set_error("pair %lld contains a byte outside the substitution matrix's alphabet", (long long)p);
+            else if (w.rc == AGX_E_SYMBOL)
                 agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)p);
             else
                 agx_set_error("pair %lld: lengths %u x %u exceed the supported %u x 65535 (shorter x longer)", (long long)p,
@@ -433,9 +501,14 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
             const uint64_t oy = off[2 * (uint64_t)pp.pair + (pp.x_is_second ^ 1)];
             uint8_t *x = (uint8_t *)(img.p + x_dw[(size_t)k]), *y = (uint8_t *)(img.p + y_dw[(size_t)k]);
             const size_t xb = (size_t)(y_dw[(size_t)k] - x_dw[(size_t)k]) * 4, yb = (((size_t)pp.ly + 3) / 4) * 4;
-            memcpy(x, bases + ox, pp.lx);
+            if (matrix) { // symbol numbers 1..n; 0 stays the padding symbol
+                for (uint32_t c = 0; c < pp.lx; ++c) x[c] = (uint8_t)(matrix->code[bases[ox + c]] + 1);
+                for (uint32_t c = 0; c < pp.ly; ++c) y[c] = (uint8_t)(matrix->code[bases[oy + c]] + 1);
+            } else {
+                memcpy(x, bases + ox, pp.lx);
+                memcpy(y, bases + oy, pp.ly);
+            }
             memset(x + pp.lx, 0, xb - pp.lx);
-            memcpy(y, bases + oy, pp.ly);
             memset(y + pp.ly, 0, yb - pp.ly);
         }
     });
@@ -450,6 +523,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     b->info.cells = cells;
     b->info.padded_cells = padded;
     b->packed = packed;
+    b->matrix = matrix != nullptr;
     b->prm = prm;
     b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
     b->info.n_launches = (int32_t)launches.size();
@@ -461,6 +535,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     rc = b->img.alloc(img.size() * 4);
     if (!rc) rc = b->groups.alloc(groups_bytes);
     if (!rc) rc = b->waves.alloc(waves.size() * sizeof(SwWave));
+    if (!rc && matrix) rc = b->table.alloc(table.size() * sizeof(int16_t));
     if (!rc) rc = b->scores.alloc(((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of empty packed halves
     if (rc) {
         agx_sw_batch_destroy(b);
@@ -472,6 +547,7 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
         e = hipMemcpy(b->groups.p, groups_data, groups_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess && !waves.empty())
         e = hipMemcpy(b->waves.p, waves.data(), waves.size() * sizeof(SwWave), hipMemcpyHostToDevice);
+    if (e == hipSuccess && matrix) e = hipMemcpy(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice);
     // pairs with an empty side are never touched by a kernel: their score is this zero
     if (e == hipSuccess) e = hipMemset(b->scores.p, 0, b->scores.bytes);
     if (e != hipSuccess) {
@@ -485,6 +561,10 @@ int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, cons
     *out = b;
     return AGX_OK;
 }
+
+} // namespace
+
+extern "C" {
 
 int agx_sw_batch_launch(agx_sw_batch *b)
 {
@@ -504,7 +584,11 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     int k = 0;
     for (const ClassLaunch &cl : b->launches) {
         hipStream_t st = fan.stream(k++);
-        const int r = b->packed
+        const int r = b->matrix
+                          ? agx_sw_mat_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
+                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
+                                                    (int32_t *)b->scores.p, (const int16_t *)b->table.p, st)
+                          : b->packed
                           ? agx_sw_pk_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                    (int32_t *)b->scores.p, st)

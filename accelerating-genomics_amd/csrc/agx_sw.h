@@ -63,6 +63,11 @@ static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 
 // same for the packed int16 kernel
 static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
 
+// substitution-matrix mode: symbol numbers 1..32 in the image, 0 = padding; the device table is
+// kSwMatDim x kSwMatDim int16 entries score - (gap_open + gap_extend)
+constexpr int kSwMatDim = 33;
+int agx_sw_mat_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
+                            const SwWave *waves, uint32_t n_waves, int32_t *scores, const int16_t *table, hipStream_t s);
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,

@@ -1,0 +1,28 @@
+// Substitution-matrix variant of the int32 Smith-Waterman kernel (agx_sw_batch_create_matrix;
+// SURVEY.md 8f n3): the same fill with the diagonal score looked up in an LDS copy of the matrix.
+// Built in its own translation unit so the classes compile in parallel with the others.
+#include "agx_sw_kernel.inc"
+
+template <int C>
+int launch(const SwParams &prm, const uint32_t *img, const SwGroup *groups, const SwWave *waves, uint32_t n_waves,
+           int32_t *scores, const int16_t *table, hipStream_t s)
+{
+    const uint32_t blocks = (n_waves + 3) / 4;
+    hipLaunchKernelGGL((sw_fill<C, true>), dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores, table);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+} // namespace
+
+int agx_sw_mat_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
+                            const SwWave *waves, uint32_t n_waves, int32_t *scores, const int16_t *table, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    switch (cols_per_lane) {
+#define AGX_SW_CASE(CC) \
+    case CC: return launch<CC>(prm, img, groups, waves, n_waves, scores, table, s);
+        AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
+#undef AGX_SW_CASE
+    default: return -2;
+    }
+}

@@ -8,7 +8,7 @@ int launch(const SwParams &prm, const uint32_t *img, const SwGroup *groups, cons
            int32_t *scores, hipStream_t s)
 {
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(sw_fill<C>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    hipLaunchKernelGGL(sw_fill<C>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores, (const int16_t *)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -292,3 +292,51 @@ def write_phmm_file(path: str, b: PhmmBatch) -> None:
                 f.write(b" ".join(x[a:z].tobytes() for x in (b.read_bases, b.q_base, b.q_ins, b.q_del, b.q_gcp)) + b"\n")
             for h in range(h0, h1):
                 f.write(b.hap_bases[int(b.hoff[h]) : int(b.hoff[h + 1])].tobytes() + b"\n")
+
+
+# ---------------------------------------------------------------- substitution matrices (8f n3)
+AMINO = b"ARNDCQEGHILKMFPSTWYV"
+# BLOSUM62 over the 20 standard residues in AMINO order (Henikoff & Henikoff 1992, half-bit units)
+BLOSUM62 = [
+    [4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0],
+    [-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3],
+    [-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3],
+    [-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3],
+    [0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1],
+    [-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2],
+    [-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2],
+    [0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3],
+    [-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3],
+    [-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3],
+    [-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1],
+    [-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2],
+    [-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1],
+    [-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1],
+    [-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2],
+    [1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2],
+    [0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0],
+    [-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3],
+    [-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1],
+    [0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4],
+]
+
+
+def protein_pairs(n_pairs: int, lmin: int, lmax: int, seed: int, related_frac: float = 0.5) -> SWBatch:
+    """Random protein pairs over AMINO; a fraction are mutated copies (15 % substitutions, 3 % indels)."""
+    rng = np.random.default_rng(seed)
+    aa = np.frombuffer(AMINO, dtype=np.uint8)
+    seqs = []
+    for _ in range(n_pairs):
+        a = aa[rng.integers(0, 20, size=int(rng.integers(lmin, lmax + 1)))]
+        if rng.random() < related_frac:
+            b = a.copy()
+            b[rng.random(b.size) < 0.15] = aa[rng.integers(0, 20)]
+            keep = rng.random(b.size) >= 0.03
+            b = b[keep]
+            if b.size == 0:
+                b = a[:1]
+            b = b[: max(1, min(b.size, lmax))]
+        else:
+            b = aa[rng.integers(0, 20, size=int(rng.integers(lmin, lmax + 1)))]
+        seqs += [a.tobytes(), b.tobytes()]
+    return sw_from_seqs(seqs)

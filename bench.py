@@ -149,6 +149,8 @@ def main():
         raise SystemExit("bench.py: no HIP device visible; libagx has no CPU fallback")
     if args.share_device:
         local_rank = 0
+    # a launcher that masks devices per rank (HIP_VISIBLE_DEVICES) leaves every rank one device, number 0
+    local_rank %= agx.device_count()
     torch.cuda.set_device(local_rank)
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if multi:

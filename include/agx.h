@@ -119,6 +119,21 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
  * against the reference program; other settings are checked against the oracle's parametrised Gotoh. */
 int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, const uint8_t *bases, const uint64_t *off,
                                const uint32_t *len, int64_t n_pairs, agx_sw_batch **out);
+/* Substitution matrix (the reference has no such mode -- its kernel's scoring
+ * arguments are ignored, hipvers.cpp:214 -- so results are checked against the oracle's Gotoh with the
+ * same matrix: "parity unpinned").  code[] maps an input byte to a symbol number 0..n_symbols-1, or
+ * 0xff for bytes outside the alphabet (such input fails with AGX_E_SYMBOL); score[a][b] is added on
+ * the diagonal move and must be symmetric (the shorter sequence of a pair is laid across the lanes
+ * whichever came first).  Gaps as in agx_sw_scoring.  Shorter side <= 2560 in this mode. */
+#define AGX_SW_MATRIX_MAX_SYMBOLS 32
+typedef struct agx_sw_matrix {
+    int32_t n_symbols; /* 1..32 */
+    int32_t gap_open, gap_extend; /* -1000..0 each */
+    uint8_t code[256];
+    int8_t score[AGX_SW_MATRIX_MAX_SYMBOLS][AGX_SW_MATRIX_MAX_SYMBOLS];
+} agx_sw_matrix;
+int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const uint8_t *bases, const uint64_t *off,
+                               const uint32_t *len, int64_t n_pairs, agx_sw_batch **out);
 /* Enqueue the fill on the context's stream; scores stay in HBM.  Asynchronous. */
 int agx_sw_batch_launch(agx_sw_batch *b);
 /* Wait for the stream and copy the scores out in the caller's pair order. */

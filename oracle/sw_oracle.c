@@ -165,6 +165,52 @@ int oracle_sw_batch_scored(const unsigned char *bases, const uint64_t *off, cons
 }
 
 /*
+ * Gotoh with a substitution matrix.  The reference has no such mode: "parity
+ * unpinned", this restatement is the only check of the product's matrix mode.  code[] maps a byte to
+ * a symbol number (every byte of the input must map below n, the caller checks); score is
+ * [32][32] row-major; gaps as in oracle_sw_score_scored.  With score[a][b] = (a == b ? match :
+ * mismatch) it equals oracle_sw_score_scored (tests/test_oracle_sw.py).
+ */
+int oracle_sw_score_matrix(const unsigned char *sx, int lx, const unsigned char *sy, int ly, const unsigned char *code,
+                           const signed char *score, int gap_open, int gap_extend)
+{
+    int *H = (int *)malloc((size_t)(lx + 1) * 2 * sizeof(int));
+    if (!H) return INT_MIN;
+    int *E = H + lx + 1;
+    const int gf = gap_open + gap_extend;
+    for (int j = 0; j <= lx; j++) { H[j] = 0; E[j] = SW_NEG_INF; }
+    int best = 0;
+    for (int iy = 1; iy <= ly; iy++) {
+        int hdiag = 0, hleft = 0, f = SW_NEG_INF;
+        const signed char *row = score + 32 * code[sy[iy - 1]];
+        for (int ix = 1; ix <= lx; ix++) {
+            int e = imax(add_inf(H[ix], gf), add_inf(E[ix], gap_extend));
+            f = imax(add_inf(hleft, gf), add_inf(f, gap_extend));
+            int s = hdiag + row[code[sx[ix - 1]]];
+            int v = imax(imax(e, f), imax(s, 0));
+            hdiag = H[ix];
+            H[ix] = v; E[ix] = e; hleft = v;
+            if (v > best) best = v;
+        }
+    }
+    free(H);
+    return best;
+}
+
+int oracle_sw_batch_matrix(const unsigned char *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
+                           int32_t *scores, const unsigned char *code, const signed char *score, int gap_open,
+                           int gap_extend)
+{
+    for (int64_t p = 0; p < n_pairs; p++) {
+        int s = oracle_sw_score_matrix(bases + off[2 * p], (int)len[2 * p], bases + off[2 * p + 1], (int)len[2 * p + 1], code,
+                                       score, gap_open, gap_extend);
+        if (s == INT_MIN) return -1;
+        scores[p] = s;
+    }
+    return 0;
+}
+
+/*
  * Batch form used by the tests and by bench.py's cpu_baseline leg:
  * seq k lives at bases+off[k], len[k] bytes; pair p = (2p, 2p+1).
  * variant 0 = antidiag port, 1 = rowmajor.

@@ -22,6 +22,8 @@ class Oracle:
         lib.oracle_sw_batch.restype = C.c_int
         lib.oracle_sw_batch_scored.argtypes = [u8p, u64p, u32p, C.c_int64, i32p, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.oracle_sw_batch_scored.restype = C.c_int
+        lib.oracle_sw_batch_matrix.argtypes = [u8p, u64p, u32p, C.c_int64, i32p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.oracle_sw_batch_matrix.restype = C.c_int
         lib.oracle_sw_file.argtypes = [C.c_char_p, i32p, C.c_long, C.POINTER(C.c_int), C.c_int]
         lib.oracle_sw_file.restype = C.c_long
         lib.oracle_pairhmm_batch.argtypes = [u8p, u8p, u8p, u8p, u8p, u64p, u8p, u64p, u32p, u32p, C.c_int,
@@ -46,6 +48,16 @@ class Oracle:
         out = np.empty(b.n_pairs, np.int32)
         bases = b.bases if b.bases.size else np.zeros(1, np.uint8)
         assert self.lib.oracle_sw_batch_scored(bases, b.off, b.len, b.n_pairs, out, *scoring) == 0
+        return out
+
+    def sw_batch_matrix(self, b, m):
+        """Gotoh with a substitution matrix; m = api.SwMatrix."""
+        out = np.empty(b.n_pairs, np.int32)
+        bases = b.bases if b.bases.size else np.zeros(1, np.uint8)
+        code = np.frombuffer(bytes(m.code), np.uint8).copy()
+        score = np.array([[m.score[a][c] for c in range(32)] for a in range(32)], np.int8)
+        assert self.lib.oracle_sw_batch_matrix(bases, b.off, b.len, b.n_pairs, out, code.ctypes.data, score.ctypes.data,
+                                               m.gap_open, m.gap_extend) == 0
         return out
 
     def sw_file(self, path, variant=0, cap=1 << 22):

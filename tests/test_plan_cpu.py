@@ -75,3 +75,34 @@ def test_phmm_plans(prec):
     q = agx.PhmmBatchDev(None, synth.phmm_regions(1, 2, 3, 10, 5000, seed=1), prec)
     assert q.info().n_launches == 1 and q.info().n_waves == 6
     q.close()
+
+
+def test_substitution_matrix_plans_and_validation():
+    """8f n3: agx_sw_batch_create_matrix validates the matrix and the alphabet on the host."""
+    m = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
+    b = synth.protein_pairs(2000, 20, 400, seed=3)
+    p = agx.SwBatch(None, b, matrix=m)
+    i = p.info()
+    assert i.n_pairs == 2000 and i.cells == b.cells(False) and i.padded_cells >= i.cells
+    p.close()
+    with pytest.raises(agx.AgxError) as e:  # 'B' is not among the 20 residues
+        agx.SwBatch(None, synth.sw_from_seqs([b"ARNB", b"ARND"]), matrix=m)
+    assert e.value.code == agx.E_SYMBOL
+    with pytest.raises(agx.AgxError) as e:  # no wide classes in matrix mode
+        agx.SwBatch(None, synth.sw_from_seqs([b"A" * 2561, b"R" * 2561]), matrix=m)
+    assert e.value.code == agx.E_LIMIT
+    bad = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
+    bad.score[3][7] = 5
+    with pytest.raises(agx.AgxError) as e:
+        agx.SwBatch(None, b, matrix=bad)
+    assert e.value.code == agx.E_ARG and "symmetric" in str(e.value)
+    for n in (0, 33):
+        bad = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
+        bad.n_symbols = n
+        with pytest.raises(agx.AgxError) as e:
+            agx.SwBatch(None, b, matrix=bad)
+        assert e.value.code == agx.E_ARG
+    bad = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, 1, -1)
+    with pytest.raises(agx.AgxError) as e:
+        agx.SwBatch(None, b, matrix=bad)
+    assert e.value.code == agx.E_LIMIT

@@ -213,3 +213,59 @@ def test_wide_classes_beyond_the_packed_kernel(ctx, oracle):
         seqs += [a, bytes(y)]
     b = synth.sw_from_seqs(seqs)
     assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b))
+
+
+def test_substitution_matrix_blosum62_vs_oracle(ctx, oracle):
+    """8f n3, "parity unpinned": the reference has no matrix mode; checked against the oracle's Gotoh
+    with the same matrix (BLAST's protein defaults: BLOSUM62, existence 11, extension 1)."""
+    m = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
+    b = synth.protein_pairs(3000, 1, 600, seed=11)
+    dev = ctx.sw_batch(b, matrix=m)
+    dev.launch()
+    dev.launch()
+    got = dev.scores()
+    dev.close()
+    ref = oracle.sw_batch_matrix(b, m)
+    assert np.array_equal(got, ref) and ref.max() > 500
+    # lower case maps to the same residues; every short length and tiling edge once
+    seqs = []
+    rng = np.random.default_rng(12)
+    aa = np.frombuffer(synth.AMINO, np.uint8)
+    for lx in list(range(1, 90)) + [159, 160, 161, 640, 1279, 1280, 1281, 2559, 2560]:
+        a = aa[rng.integers(0, 20, size=lx)].tobytes()
+        y = aa[rng.integers(0, 20, size=lx + int(rng.integers(0, 40)))].tobytes()
+        seqs += [a.lower() if lx % 2 else a, y[: lx // 2] + a[lx // 3 :] + y[lx // 2 :]]
+    b = synth.sw_from_seqs(seqs)
+    assert np.array_equal(_scores(ctx, b, m), oracle.sw_batch_matrix(b, m))
+
+
+def _scores(ctx, b, m):
+    dev = ctx.sw_batch(b, matrix=m)
+    dev.launch()
+    out = dev.scores()
+    dev.close()
+    return out
+
+
+@pytest.mark.parametrize("scoring", [(1, -1, -3, -1), (2, -3, -5, -2), (5, -4, -10, 0)])
+def test_match_mismatch_matrix_equals_runtime_scoring(ctx, oracle, scoring):
+    """A matrix holding match on the diagonal and mismatch elsewhere must give the scores of
+    agx_sw_batch_create_scored -- at (1,-1,-3,-1) the reference's own."""
+    match, mis, go, ge = scoring
+    b = synth.sw_pairs(2000, 1, 300, seed=21, related_frac=0.5)
+    m = agx.SwMatrix.build(b"ACGT\n", [[match if a == c else mis for c in range(5)] for a in range(5)], go, ge)
+    got = _scores(ctx, b, m)
+    dev = ctx.sw_batch(b, scoring)
+    dev.launch()
+    assert np.array_equal(got, dev.scores())
+    dev.close()
+    assert np.array_equal(got, oracle.sw_batch_scored(b, scoring))
+
+
+def test_matrix_with_no_negative_entry_and_empty_sides(ctx, oracle):
+    m = agx.SwMatrix.build(b"AB", [[2, 0], [0, 3]], 0, -1)
+    b = synth.sw_from_seqs([b"", b"AB", b"ABBA", b"", b"ABABAB", b"BBBAAA", b"A", b"B"])
+    assert np.array_equal(_scores(ctx, b, m), oracle.sw_batch_matrix(b, m))
+    with pytest.raises(agx.AgxError) as e:
+        _scores(ctx, synth.sw_from_seqs([b"ABC", b"AB"]), m)
+    assert e.value.code == agx.E_SYMBOL

@@ -26,3 +26,8 @@ p = synth.phmm_regions(16, 32, 16, 250, 5000, seed=6)
 for prec, pn in ((agx.PHMM_F64, "f64"), (agx.PHMM_F64_FMA, "fma")):
     dev = ctx.phmm_batch(p, prec); info = dev.info(); ms = timeit(dev, 2)
     print("PHMM long 250x5000 %s: %.3f ms %.3f Mpairs/s %.1f GCUPS eff %.3f waves %d" % (pn, ms, p.n_pairs/ms/1e3, info.cells/ms/1e6, info.cells/info.padded_cells, info.n_waves), flush=True); dev.close()
+# substitution-matrix mode (int32 kernel + LDS lookup) and the int32 kernel itself for comparison
+m = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
+b = synth.protein_pairs(65536, 150, 150, seed=2, related_frac=0.25)
+dev = ctx.sw_batch(b, matrix=m); info = dev.info(); ms = timeit(dev, 20)
+print("SW BLOSUM62 65536x~150x150: %.4f ms %.0f GCUPS eff %.3f" % (ms, info.cells/ms/1e6, info.cells/info.padded_cells), flush=True); dev.close()
