@@ -23,7 +23,8 @@ SYMBOLS = [
     "agx_sw_score", "agx_sw_score_multi",
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
     "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_pairHMM",
-    "agx_sw_text_read", "agx_sw_text_free", "agx_phmm_text_read", "agx_phmm_text_free",
+    "agx_sw_text_read", "agx_sw_text_free", "agx_sw_reader_open", "agx_sw_reader_line_num", "agx_sw_reader_next",
+    "agx_sw_reader_done", "agx_sw_reader_close", "agx_phmm_text_read", "agx_phmm_text_free",
 ]
 
 
@@ -137,6 +138,13 @@ def lib():
         l.agx_sw_text_read.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.POINTER(SwText))]
         l.agx_sw_text_free.argtypes = [C.POINTER(SwText)]
         l.agx_sw_text_free.restype = None
+        l.agx_sw_reader_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        l.agx_sw_reader_line_num.argtypes = [C.c_void_p]
+        l.agx_sw_reader_line_num.restype = C.c_int32
+        l.agx_sw_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(SwText))]
+        l.agx_sw_reader_done.argtypes = [C.c_void_p]
+        l.agx_sw_reader_close.argtypes = [C.c_void_p]
+        l.agx_sw_reader_close.restype = None
         l.agx_phmm_text_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(PhmmText))]
         l.agx_phmm_text_free.argtypes = [C.POINTER(PhmmText)]
         l.agx_phmm_text_free.restype = None
@@ -316,21 +324,42 @@ def phmm_forward_multi(b, precision=PHMM_F64, n_devices: int = 0) -> np.ndarray:
     return out
 
 
-def read_sw_text(path: str, line_buf: int = 0):
-    """agx_sw_text_read -> (line_num, synth.SWBatch, dangling line or None)."""
+def _sw_text_to_batch(t):
     from . import synth
 
-    t = C.POINTER(SwText)()
-    _check(lib().agx_sw_text_read(path.encode(), line_buf, C.byref(t)))
-    try:
+    if True:
         n = t.contents.n_pairs
         off = np.ctypeslib.as_array(C.cast(t.contents.off, C.POINTER(C.c_uint64)), shape=(2 * n,)).copy() if n else np.zeros(0, np.uint64)
         ln = np.ctypeslib.as_array(C.cast(t.contents.len, C.POINTER(C.c_uint32)), shape=(2 * n,)).copy() if n else np.zeros(0, np.uint32)
         total = int(off[-1] + ln[-1]) if n else 0
         bases = np.ctypeslib.as_array(C.cast(t.contents.bases, C.POINTER(C.c_uint8)), shape=(total,)).copy() if total else np.zeros(0, np.uint8)
         return t.contents.line_num, synth.SWBatch(bases, off, ln), t.contents.dangling
+
+
+def read_sw_text(path: str, line_buf: int = 0):
+    """agx_sw_text_read -> (line_num, synth.SWBatch, dangling line or None)."""
+    t = C.POINTER(SwText)()
+    _check(lib().agx_sw_text_read(path.encode(), line_buf, C.byref(t)))
+    try:
+        return _sw_text_to_batch(t)
     finally:
         lib().agx_sw_text_free(t)
+
+
+def read_sw_text_chunks(path: str, max_pairs: int, line_buf: int = 0):
+    """agx_sw_reader_*: yields (line_num, synth.SWBatch, dangling) per chunk of up to max_pairs pairs."""
+    r = C.c_void_p()
+    _check(lib().agx_sw_reader_open(path.encode(), line_buf, C.byref(r)))
+    try:
+        while not lib().agx_sw_reader_done(r):
+            t = C.POINTER(SwText)()
+            _check(lib().agx_sw_reader_next(r, max_pairs, C.byref(t)))
+            try:
+                yield _sw_text_to_batch(t)
+            finally:
+                lib().agx_sw_text_free(t)
+    finally:
+        lib().agx_sw_reader_close(r)
 
 
 def read_phmm_text(path: str):

@@ -637,9 +637,15 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
     agx_sw_batch *b = nullptr;
     int rc = agx_sw_batch_create(ctx, bases, off, len, n_pairs, &b);
     if (rc) return rc;
+    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     rc = agx_sw_batch_launch(b);
+    const double t1 = now();
     if (!rc) rc = agx_sw_batch_scores(b, scores);
+    const double t2 = now();
     agx_sw_batch_destroy(b);
+    if (trace) fprintf(stderr, "[agx_sw_score] launch %.2f ms, wait+D2H %.2f ms, destroy %.2f ms\n", t1 - t0, t2 - t1, now() - t2);
     return rc;
 }
 

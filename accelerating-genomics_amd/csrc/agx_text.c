@@ -54,49 +54,155 @@ void agx_sw_text_free(agx_sw_text *t)
     free(t);
 }
 
-int agx_sw_text_read(const char *path, int line_buf, agx_sw_text **out)
+/*
+ * Block reader with fgets() semantics: a "line" is the bytes up to and including the next '\n', at
+ * most line_buf-1 of them (longer lines split there), or what is left at end of file.  The block
+ * is scanned with memchr instead of byte by byte; the strlen() the reference applies to the fgets
+ * buffer (a NUL byte in the file hides the rest of the line) is applied to the line found.
+ */
+struct agx_sw_reader {
+    FILE *f;
+    int line_buf;
+    int32_t line_num;
+    int64_t lines_taken; /* the reference's loop variable i (:216): sequence lines consumed so far */
+    int finished;
+    char *buf;
+    size_t cap, lo, hi;
+    int eof;
+};
+
+/* next line -> *p (valid until the next call), its strlen() in *n; 0 = no line left */
+static int reader_line(agx_sw_reader *r, const char **p, size_t *n)
+{
+    const size_t max = (size_t)r->line_buf - 1;
+    for (;;) {
+        const size_t have = r->hi - r->lo;
+        const size_t look = have < max ? have : max;
+        const char *nl = look ? (const char *)memchr(r->buf + r->lo, '\n', look) : NULL;
+        size_t len = 0;
+        if (nl) len = (size_t)(nl - (r->buf + r->lo)) + 1;
+        else if (look == max) len = max;       /* split an over-long line where fgets would */
+        else if (r->eof) len = have;           /* last line without a newline */
+        else {                                 /* need more bytes */
+            if (r->lo) {
+                memmove(r->buf, r->buf + r->lo, have);
+                r->lo = 0;
+                r->hi = have;
+            }
+            const size_t got = fread(r->buf + r->hi, 1, r->cap - r->hi, r->f);
+            r->hi += got;
+            if (got == 0) r->eof = 1;
+            continue;
+        }
+        if (len == 0) return 0;
+        *p = r->buf + r->lo;
+        const char *z = (const char *)memchr(*p, 0, len);
+        *n = z ? (size_t)(z - *p) : len;
+        r->lo += len;
+        return 1;
+    }
+}
+
+void agx_sw_reader_close(agx_sw_reader *r)
+{
+    if (!r) return;
+    if (r->f) fclose(r->f);
+    free(r->buf);
+    free(r);
+}
+
+int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out)
 {
     if (!out || !path) {
-        agx_set_error("agx_sw_text_read: null argument");
+        agx_set_error("agx_sw_reader_open: null argument");
         return AGX_E_ARG;
     }
     *out = NULL;
     if (line_buf <= 0) line_buf = 1000; /* MAX_LINE_LENGTH, antidiagonalSmithWaterman.c:44 */
     if (line_buf < 2) {
-        agx_set_error("agx_sw_text_read: line buffer too small");
+        agx_set_error("agx_sw_reader_open: line buffer too small");
         return AGX_E_ARG;
     }
-    FILE *f = fopen(path, "r");
-    if (!f) {
+    agx_sw_reader *r = (agx_sw_reader *)calloc(1, sizeof *r);
+    if (!r) {
+        agx_set_error("agx_sw_reader_open: out of memory");
+        return AGX_E_NOMEM;
+    }
+    r->line_buf = line_buf;
+    r->cap = (size_t)4 << 20;
+    if (r->cap < 2 * (size_t)line_buf) r->cap = 2 * (size_t)line_buf;
+    r->buf = (char *)malloc(r->cap);
+    r->f = fopen(path, "r");
+    if (!r->f) {
         agx_set_error("Error opening file: %s", strerror(errno));
+        agx_sw_reader_close(r);
         return AGX_E_IO;
     }
-    int rc = AGX_E_NOMEM;
-    char *l1 = (char *)malloc((size_t)line_buf), *l2 = (char *)malloc((size_t)line_buf);
+    if (!r->buf) {
+        agx_set_error("agx_sw_reader_open: out of memory");
+        agx_sw_reader_close(r);
+        return AGX_E_NOMEM;
+    }
+    setvbuf(r->f, NULL, _IONBF, 0); /* the reader has its own block buffer */
+    const char *p;
+    size_t n;
+    if (!reader_line(r, &p, &n)) { /* :205-208 */
+        agx_set_error("file is empty");
+        agx_sw_reader_close(r);
+        return AGX_E_IO;
+    }
+    char head[32];
+    const size_t hn = n < sizeof head - 1 ? n : sizeof head - 1;
+    memcpy(head, p, hn);
+    head[hn] = 0;
+    r->line_num = atoi(head); /* number of sequence LINES, :209 */
+    *out = r;
+    return AGX_OK;
+}
+
+int32_t agx_sw_reader_line_num(const agx_sw_reader *r) { return r ? r->line_num : -1; }
+
+int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
+{
+    if (!r || !out) {
+        agx_set_error("agx_sw_reader_next: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
     agx_sw_text *t = (agx_sw_text *)calloc(1, sizeof *t);
     buf_t bases = {0}, off = {0}, len = {0};
-    if (!l1 || !l2 || !t) goto done;
-    if (!fgets(l1, line_buf, f)) { /* ":205-208" file is empty */
-        agx_set_error("file is empty");
-        rc = AGX_E_IO;
-        t->line_num = -1;
-        goto done;
-    }
-    t->line_num = atoi(l1); /* number of sequence LINES, :209 */
-    for (int i = 0; i < t->line_num; i += 2) {
-        if (!fgets(l1, line_buf, f)) break; /* :219-221 */
-        if (!fgets(l2, line_buf, f)) {      /* :223-227: the first line is echoed, loop ends */
-            t->dangling = strdup(l1);
-            if (!t->dangling) goto done;
+    int rc = AGX_E_NOMEM;
+    if (!t) goto done;
+    t->line_num = r->line_num;
+    while (!r->finished && t->n_pairs < max_pairs) {
+        if (r->lines_taken >= r->line_num) { /* loop condition of :216 */
+            r->finished = 1;
             break;
         }
-        const char *s[2] = {l1, l2};
-        for (int k = 0; k < 2; k++) {
-            uint64_t o = bases.n;
-            uint32_t n = (uint32_t)strlen(s[k]); /* newline included, :229-247 */
-            if (buf_put(&bases, s[k], n) || buf_put(&off, &o, sizeof o) || buf_put(&len, &n, sizeof n)) goto done;
+        const char *p;
+        size_t n1, n2;
+        if (!reader_line(r, &p, &n1)) { /* :219-221 */
+            r->finished = 1;
+            break;
         }
+        const uint64_t o1 = bases.n;
+        if (buf_put(&bases, p, n1)) goto done;
+        if (!reader_line(r, &p, &n2)) { /* :223-227: the first line is echoed, loop ends */
+            t->dangling = (char *)malloc(n1 + 1);
+            if (!t->dangling) goto done;
+            memcpy(t->dangling, bases.p + o1, n1);
+            t->dangling[n1] = 0;
+            bases.n = (size_t)o1;
+            r->finished = 1;
+            break;
+        }
+        const uint64_t o2 = bases.n;
+        const uint32_t l1 = (uint32_t)n1, l2 = (uint32_t)n2; /* newline included, :229-247 */
+        if (buf_put(&bases, p, n2) || buf_put(&off, &o1, sizeof o1) || buf_put(&len, &l1, sizeof l1) ||
+            buf_put(&off, &o2, sizeof o2) || buf_put(&len, &l2, sizeof l2))
+            goto done;
         t->n_pairs++;
+        r->lines_taken += 2;
     }
     t->bases = bases.p;
     t->off = (uint64_t *)off.p;
@@ -104,18 +210,32 @@ int agx_sw_text_read(const char *path, int line_buf, agx_sw_text **out)
     bases.p = off.p = len.p = NULL;
     rc = AGX_OK;
 done:
-    fclose(f);
-    free(l1);
-    free(l2);
     free(bases.p);
     free(off.p);
     free(len.p);
-    if (rc == AGX_E_NOMEM) agx_set_error("agx_sw_text_read: out of memory");
     if (rc != AGX_OK) {
+        agx_set_error("agx_sw_reader_next: out of memory");
         agx_sw_text_free(t);
         t = NULL;
     }
     *out = t;
+    return rc;
+}
+
+int agx_sw_reader_done(const agx_sw_reader *r) { return !r || r->finished; }
+
+int agx_sw_text_read(const char *path, int line_buf, agx_sw_text **out)
+{
+    if (!out || !path) {
+        agx_set_error("agx_sw_text_read: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
+    agx_sw_reader *r = NULL;
+    int rc = agx_sw_reader_open(path, line_buf, &r);
+    if (rc != AGX_OK) return rc;
+    rc = agx_sw_reader_next(r, INT64_MAX, out);
+    agx_sw_reader_close(r);
     return rc;
 }
 

@@ -246,6 +246,18 @@ typedef struct agx_sw_text {
 int agx_sw_text_read(const char *path, int line_buf /* 0 = reference's 1000 */, agx_sw_text **out);
 void agx_sw_text_free(agx_sw_text *t);
 
+/* The same reader in pieces, so a host can score one chunk while the next is being parsed
+ * (host/antidiagonalSmithWaterman.c does).  open reads the header; every next() returns a fresh
+ * agx_sw_text object, which the caller frees, with up to max_pairs further pairs -- offsets relative to that
+ * chunk's bases -- and `dangling` on the chunk that met an unpaired last line; done() turns 1 once
+ * the reference's loop would have ended (header count reached or input exhausted). */
+typedef struct agx_sw_reader agx_sw_reader;
+int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out);
+int32_t agx_sw_reader_line_num(const agx_sw_reader *r);
+int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out);
+int agx_sw_reader_done(const agx_sw_reader *r);
+void agx_sw_reader_close(agx_sw_reader *r);
+
 typedef struct agx_phmm_text {
     agx_phmm_desc desc; /* points into storage owned by this object */
     int64_t n_pairs;

@@ -101,3 +101,50 @@ def test_phmm_text_reader_truncated_region(tmp_path, golden_dir):
     (tmp_path / "cut.in").write_bytes(b"\n".join(data[:14]) + b"\n")  # region 1 = 1+6+4 lines, region 2 cut short
     got, seen, trunc = agx.read_phmm_text(str(tmp_path / "cut.in"))
     assert trunc == 1 and seen == 2 and got.n_regions == 1 and got.n_pairs == 24
+
+
+def _fgets_lines(data: bytes, bufsz: int):
+    """What a loop of fgets(buf, bufsz) + strlen(buf) sees (antidiagonalSmithWaterman.c:219-247)."""
+    pos = 0
+    while pos < len(data):
+        chunk = data[pos:pos + bufsz - 1]
+        i = chunk.find(b"\n")
+        line = chunk[:i + 1] if i >= 0 else chunk
+        pos += len(line)
+        z = line.find(b"\0")
+        yield line if z < 0 else line[:z]
+
+
+@pytest.mark.parametrize("seed,final_newline", [(1, True), (2, False), (3, True)])
+def test_block_reader_has_fgets_semantics_and_chunks_concatenate(tmp_path, seed, final_newline):
+    """The memchr block reader against a byte-level model of fgets/strlen: over-long lines split at
+    bufsz-1, a NUL hides the rest of its line, the last line may lack its newline; reading in chunks
+    (agx_sw_reader_next) gives the same pairs as reading at once."""
+    rng = np.random.default_rng(seed)
+    lens = [0, 1, 5, 998, 999, 1000, 1001, 1997, 1998, 1999, 2500] + [int(x) for x in rng.integers(1, 1200, size=90)]
+    rng.shuffle(lens)
+    body = b""
+    for k, n in enumerate(lens):
+        line = bytearray(rng.choice(list(b"ACGT"), size=n).tolist())
+        if k % 17 == 5 and n > 3:
+            line[n // 2] = 0
+        body += bytes(line) + b"\n"
+    if not final_newline:
+        body = body[:-1]
+    for header in (b"100000\n", b"61\n", b"6\n"):
+        p = tmp_path / "f.in"
+        p.write_bytes(header + body)
+        want = list(_fgets_lines(body, 1000))[: int(header) + (int(header) & 1)]
+        dangling = want[-1] if len(want) % 2 else None
+        want = want[: len(want) // 2 * 2]
+        line_num, b, dang = agx.read_sw_text(str(p))
+        assert line_num == int(header) and b.n_pairs == len(want) // 2
+        assert [b.seq(k) for k in range(2 * b.n_pairs)] == want
+        assert dang == dangling
+        for chunk in (1, 7, 10 ** 6):
+            got, dangs = [], []
+            for ln, cb, d in agx.read_sw_text_chunks(str(p), chunk):
+                assert ln == int(header) and cb.n_pairs <= chunk
+                got += [cb.seq(k) for k in range(2 * cb.n_pairs)]
+                dangs.append(d)
+            assert got == want and [d for d in dangs if d is not None] == ([dangling] if dangling is not None else [])
