@@ -39,6 +39,35 @@ static void sw_file(const char *dir, const char *name, int line_buf)
     rc = agx_sw_batch_create_scored(NULL, &sc, t->bases, t->off, t->len, t->n_pairs, &b);
     EXPECT(rc == AGX_OK);
     agx_sw_batch_destroy(b);
+    b = NULL;
+    /* substitution-matrix mode over every byte the file holds (newline included) */
+    agx_sw_matrix m;
+    memset(&m, 0, sizeof m);
+    m.n_symbols = 6;
+    m.gap_open = -4;
+    m.gap_extend = -1;
+    memset(m.code, 0xff, sizeof m.code);
+    const char *alpha = "ACGTN\n";
+    for (int k = 0; k < 6; k++) m.code[(unsigned char)alpha[k]] = (uint8_t)k;
+    for (int a = 0; a < 6; a++)
+        for (int c = 0; c < 6; c++) m.score[a][c] = (int8_t)(a == c ? 3 : -2);
+    rc = agx_sw_batch_create_matrix(NULL, &m, t->bases, t->off, t->len, t->n_pairs, &b);
+    EXPECT(rc == AGX_OK || rc == AGX_E_SYMBOL || rc == AGX_E_LIMIT); /* split lines / other bytes / long lines */
+    agx_sw_batch_destroy(b);
+    /* the same file through the chunked reader: same number of pairs */
+    agx_sw_reader *r = NULL;
+    EXPECT(agx_sw_reader_open(path, line_buf, &r) == AGX_OK && r);
+    int64_t n = 0;
+    while (r && !agx_sw_reader_done(r)) {
+        agx_sw_text *c = NULL;
+        EXPECT(agx_sw_reader_next(r, 3, &c) == AGX_OK && c);
+        if (!c) break;
+        EXPECT(c->n_pairs <= 3 && c->line_num == t->line_num);
+        n += c->n_pairs;
+        agx_sw_text_free(c);
+    }
+    EXPECT(n == t->n_pairs);
+    agx_sw_reader_close(r);
     agx_sw_text_free(t);
 }
 
@@ -73,7 +102,7 @@ int main(int argc, char **argv)
         sw_file(argv[1], sw[i], 10000);
         sw_file(argv[1], sw[i], 16); /* tiny buffer: every line splits many times */
     }
-    const char *ph[] = {"phmm_test.in", "phmm_10s.in", "phmm_synth.in", "phmm_far.in"};
+    const char *ph[] = {"phmm_test.in", "phmm_10s.in", "phmm_synth.in", "phmm_far.in", "phmm_long.in"};
     for (size_t i = 0; i < sizeof ph / sizeof ph[0]; i++) phmm_file(argv[1], ph[i]);
     /* wrong formats fed to each reader must fail or parse without touching invalid memory */
     agx_phmm_text *pt = NULL;
