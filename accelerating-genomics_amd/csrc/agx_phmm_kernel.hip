@@ -226,9 +226,16 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
             }
             if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
                 if constexpr (CHAIN) {
+                    // (the lanes active in this block share gl: the test is uniform in practice and
+                    // interior lanes skip the per-column masks)
+                    if (col0 + C <= H) {
 #pragma unroll
-                    for (int j = 0; j < C; ++j)
-                        if (col0 + j < H) acc += (M[j] + X[j]);
+                        for (int j = 0; j < C; ++j) acc += (M[j] + X[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < C; ++j)
+                            if (col0 + j < H) acc += (M[j] + X[j]);
+                    }
                     if (gl == G - 1) result = acc;
                 } else {
 #pragma unroll

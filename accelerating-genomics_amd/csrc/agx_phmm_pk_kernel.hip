@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
         Y[j] = init;
     }
     f2 pM = splat(0.f), pX = splat(0.f), pY = init;
-    // every lane sums its columns of the last row in double; the lanes are combined after the loop
+    // every lane sums its own columns of the last row; the lanes are combined in double after the loop
     // (a float running sum over thousands of columns would lose the 1e-6 the mode promises)
     double part_a = 0, part_b = 0;
     const int steps = (int)w.steps;
@@ -189,14 +189,36 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
                 cY = y;
                 Y[j] = y;
             }
-            if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+            if (t - gl + 1 == R) { // last read row: likelihood (:206-212)
+                // This block runs once per lane position (G times per wave, a few lanes each), so it is
+                // kept short: four float accumulators per half (at most 8 terms each: the rounding stays
+                // below 3e-7 of the lane's sum), one conversion to double per half.  Lanes whose columns
+                // all lie inside both haplotypes -- all of a step's active lanes share gl -- skip the masks.
+                f2 a0 = splat(0.f), a1 = splat(0.f), a2 = splat(0.f), a3 = splat(0.f);
+                if (col0 + C <= HA && col0 + C <= HB) {
 #pragma unroll
-                for (int j = 0; j < C; ++j) {
-                    if (col0 + j < HA) part_a += (double)(M[j].x + X[j].x);
-                    if (col0 + j < HB) part_b += (double)(M[j].y + X[j].y);
-                    // keep the conversions next to their adds (register pressure)
-                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < C; ++j) {
+                        const f2 v = M[j] + X[j];
+                        if ((j & 3) == 0) a0 += v;
+                        if ((j & 3) == 1) a1 += v;
+                        if ((j & 3) == 2) a2 += v;
+                        if ((j & 3) == 3) a3 += v;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < C; ++j) {
+                        f2 v = M[j] + X[j];
+                        if (col0 + j >= HA) v.x = 0.f;
+                        if (col0 + j >= HB) v.y = 0.f;
+                        if ((j & 3) == 0) a0 += v;
+                        if ((j & 3) == 1) a1 += v;
+                        if ((j & 3) == 2) a2 += v;
+                        if ((j & 3) == 3) a3 += v;
+                    }
                 }
+                const f2 tot = (a0 + a1) + (a2 + a3);
+                part_a = (double)tot.x;
+                part_b = (double)tot.y;
             }
         }
     };

@@ -154,9 +154,14 @@ phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ 
                         out[2u * scratch_rows + t] = Y[C - 1];
                     }
                     if (t - lane + 1 == R) {
+                        if (col0 + C <= H) { // interior lane: no per-column masks
 #pragma unroll
-                        for (int j = 0; j < C; ++j)
-                            if (col0 + j < H) acc += (M[j] + X[j]);
+                            for (int j = 0; j < C; ++j) acc += (M[j] + X[j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < C; ++j)
+                                if (col0 + j < H) acc += (M[j] + X[j]);
+                        }
                         if (lane == G - 1) result = acc;
                     }
                     acc_prev = acc;
