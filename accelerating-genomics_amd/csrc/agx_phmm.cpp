@@ -298,6 +298,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     };
     auto make_plan = [&](int kind, int slots, bool rows_f64, PlanOut &po) -> int {
         const ClassTable ct = class_table(kind);
+        auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
         std::vector<Plan> gen = gen0;
         std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
         for (Plan &p : gen) {
@@ -373,7 +374,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                     const Plan &p = plan[i];
                     const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
                     const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                    if (n > 0 && ntabs_new > 1 && ph_tab_bytes(rows_f64, gatk_prior, nsteps + G - 1) * ntabs_new > kTabBudget) break;
+                    if (n > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > kTabBudget) break;
                     if (p.read != last_read) {
                         put_read(p.read);
                         po.tabs.push_back(PhTab{read_dw[p.read], p.R});
@@ -424,7 +425,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 w.n_groups = (uint16_t)n;
                 w.n_tabs = (uint16_t)ntabs;
                 w.steps = steps;
-                cl.lds = std::max(cl.lds, ph_tab_bytes(rows_f64, gatk_prior, steps + G - 1) * ntabs);
+                cl.lds = std::max(cl.lds, tab_bytes(rows_f64, steps + G - 1) * ntabs);
                 cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
                 po.padded += (int64_t)steps * 64 * cl.C * slots;
                 po.waves.push_back(w);

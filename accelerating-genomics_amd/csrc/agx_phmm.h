@@ -78,6 +78,9 @@ __host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, ui
     return (ph_row_bytes(f64, mis_col) * rows + 15u) & ~(size_t)15u;
 }
 
+// the packed float kernel's tables: one 32-byte row of derived values per read position
+__host__ __device__ static inline size_t ph_pk_tab_bytes(uint32_t rows) { return (size_t)rows * 32u; }
+
 // mode: 0 = f64 reference order, 1 = f64 with FMA contraction, 2 = f32, 3 = f64 rescue pass
 // over an f32 result (only groups whose sums[out] < rescue_below are recomputed), 4 = f64
 // reference order with probability tracks instead of Phred characters (pairHMM() seam).

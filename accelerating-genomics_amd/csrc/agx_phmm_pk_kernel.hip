@@ -63,43 +63,40 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
     const int R = (int)(g.R_tab & 0xffffu);
     const int HA = (int)g.H[0], HB = (int)g.H[1];
 
-    // ---- read tables -> LDS (as in agx_phmm_kernel.hip, float rows)
+    // ---- read tables -> LDS.  One 32-byte row per read position holds what the cell loop consumes,
+    // already derived: {1-Qr, mismatch prior, 1-(Qi+Qd), 1-Qg | Qi, Qd, Qg, base} -- the same float
+    // operations p()/mm() prescribe (:111-117), done once per row here instead of once per lane and
+    // step; a lane fetches its row with two ds_read_b128 from one address.  Neutral rows (before
+    // the read and behind it): priors irrelevant, mm = 1, 1-Qg = 0, Qi = Qd = 0, Qg = 1.
     const uint32_t rows = w.steps + (uint32_t)G - 1u;
-    const bool mis_col = lut_mis != nullptr;
-    const uint32_t ncol = mis_col ? 5u : 4u;
-    const size_t tab_bytes = ph_tab_bytes(false, mis_col, rows);
+    const size_t tab_bytes = ph_pk_tab_bytes(rows);
     for (uint32_t k = 0; k < w.n_tabs; ++k) {
         const PhTab tb = tabs[w.first_tab + k];
-        float *tq = reinterpret_cast<float *>(lds + k * tab_bytes);
-        unsigned char *tc = reinterpret_cast<unsigned char *>(tq + ncol * rows);
+        float4 *tr = reinterpret_cast<float4 *>(lds + k * tab_bytes);
         const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
         const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
         for (uint32_t r = lane; r < rows; r += 64) {
             const int i = (int)r - (G - 1);
             float vr = 0, vi = 0, vd = 0, vg = 1, vm = 0; // neutral row
-            unsigned char c = 0;
+            uint32_t c = 0;
             if (i >= 0 && i < (int)tb.R) {
                 c = rp[i];
                 vr = lut[rp[trk + i]];
-                if (mis_col) vm = lut_mis[rp[trk + i]];
+                vm = lut_mis ? lut_mis[rp[trk + i]] : vr; // Qr/3 with AGX_PHMM_GATK_PRIOR, else Qr itself
                 vi = lut[rp[2 * trk + i]];
                 vd = lut[rp[3 * trk + i]];
                 vg = lut[rp[4 * trk + i]];
             }
-            tq[r] = vr;
-            tq[rows + r] = vi;
-            tq[2 * rows + r] = vd;
-            tq[3 * rows + r] = vg;
-            if (mis_col) tq[4 * rows + r] = vm;
-            tc[r] = c;
+            const float pm = 1 - vr;                          // p(): match or N
+            const float pq = c == (uint32_t)'N' ? pm : vm;    //      mismatch
+            tr[2 * r] = float4{pm, pq, 1 - (vi + vd), 1 - vg}; // mm() (:115-117)
+            tr[2 * r + 1] = float4{vi, vd, vg, __uint_as_float(c)};
         }
     }
     __syncthreads();
 
-    const uint32_t mis_off = mis_col ? 4u * rows : 0u;
     const uint32_t tabi = g.R_tab >> 16;
-    const float *tq = reinterpret_cast<const float *>(lds + tabi * tab_bytes) + (G - 1 - gl);
-    const unsigned char *tc = reinterpret_cast<const unsigned char *>(lds + tabi * tab_bytes + ncol * rows * sizeof(float)) + (G - 1 - gl);
+    const float4 *trow = reinterpret_cast<const float4 *>(lds + tabi * tab_bytes) + 2 * (G - 1 - gl);
 
     // this lane's C bases of both haplotypes, one register per column: a | b << 16
     uint32_t hq[C];
@@ -145,13 +142,11 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
     auto fill = [&](auto hapn_tag) {
         constexpr bool HAPN = decltype(hapn_tag)::value;
         for (int t = 0; t < steps; ++t) {
-            const float q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
-            const float q_m = tq[mis_off + t];
-            const uint32_t rc = tc[t];
-            const float pm = 1 - q_r;                        // p(): match or N
-            const float pq = rc == (uint32_t)'N' ? pm : q_m; //      mismatch
-            const f2 mm = splat(1 - (q_i + q_d)), gm = splat(1 - q_g);
-            const f2 qi = splat(q_i), qd = splat(q_d), qg = splat(q_g);
+            const float4 ra = trow[2 * t], rb = trow[2 * t + 1];
+            const float pm = ra.x, pq = ra.y;
+            const uint32_t rc = __float_as_uint(rb.w);
+            const f2 mm = splat(ra.z), gm = splat(ra.w);
+            const f2 qi = splat(rb.x), qd = splat(rb.y), qg = splat(rb.z);
 
             f2 lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
             if (start) { // column 0 of rows >= 1 (:168-178)
