@@ -46,8 +46,9 @@ int max_cols_per_lane()
     return v;
 }
 
-// AGX_PHMM_FORCE_C pins the class (calibration runs only).
-int force_cols_per_lane()
+// AGX_PHMM_FORCE_C pins the class (calibration runs only); a class table without that width
+// ignores it (e.g. the double rescue plan of a packed float batch forced to an odd width).
+int force_cols_per_lane_raw()
 {
     static const int v = [] {
         const char *e = getenv("AGX_PHMM_FORCE_C");
@@ -70,6 +71,14 @@ ClassTable class_table(int kind)
     return ClassTable{kPhClasses, kPhClassCost[kind], kPhNumClasses};
 }
 
+int force_cols_per_lane(const ClassTable &ct)
+{
+    const int f = force_cols_per_lane_raw();
+    for (int ci = 0; f && ci < ct.n; ++ci)
+        if (ct.C[ci] == f && ct.cost[ci] != 0) return f;
+    return 0;
+}
+
 void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
 {
     const ClassTable ct = class_table(precision);
@@ -80,7 +89,7 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t 
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
         if (C > max_cols_per_lane() && best >= 0) continue;
-        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        if (force_cols_per_lane(ct) && C != force_cols_per_lane(ct)) continue;
         const double wgt = ct.cost[ci];
         if (wgt == 0) continue; // class not built for this arithmetic
         const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G)) * wgt;
@@ -106,7 +115,7 @@ void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count,
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
         if (C > max_cols_per_lane() && best >= 0) continue;
-        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+        if (force_cols_per_lane(ct) && C != force_cols_per_lane(ct)) continue;
         const double wgt = ct.cost[ci];
         if (wgt == 0) continue;
         const int64_t per_wave = 64 / G;

@@ -57,8 +57,8 @@ struct PhWave {
 // haplotype over all 64 lanes where the even ones leave lanes idle, e.g. H = 300 = 16 lanes x 19)
 static const int kPhPkClasses[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30};
 static const int kPhPkNumClasses = sizeof(kPhPkClasses) / sizeof(kPhPkClasses[0]);
-// measured for the even widths (profiles/r01_calibration.log), interpolated for the odd ones
-static const double kPhPkClassCost[] = {2.136, 1.914, 1.692, 1.570, 1.449, 1.393, 1.336, 1.292, 1.248, 1.203, 1.159, 1.147, 1.136, 1.133, 1.131, 1.117, 1.103, 1.100, 1.098, 1.079, 1.061, 1.047, 1.033, 1.016, 1.000, 1.107, 1.215};
+// measured for every width (profiles/r01_calibration.log, "packed float kernel, third calibration")
+static const double kPhPkClassCost[] = {1.834, 1.541, 1.454, 1.332, 1.293, 1.220, 1.195, 1.141, 1.137, 1.098, 1.093, 1.083, 1.073, 1.059, 1.063, 1.073, 1.068, 1.044, 1.034, 1.049, 1.034, 1.024, 1.024, 1.029, 1.020, 1.005, 1.000};
 static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic

@@ -29,6 +29,7 @@ if what == "sw":
 else:
     p = synth.phmm_regions(192, 32, 16, 128, 8*C, seed=2)
     for prec, name in ((agx.PHMM_F32, "f32"), (agx.PHMM_F64, "f64"), (agx.PHMM_F64_FMA, "fma"), (agx.PHMM_F32_FMA, "pkf")):
+        if os.environ.get("CAL_ONLY_PKF") and name != "pkf": continue
         if C > 32 and prec != agx.PHMM_F32: continue
         if C > 30 and prec == agx.PHMM_F32_FMA: continue
         dev = ctx.phmm_batch(p, prec); i = dev.info(); ms = timeit(dev, 3)
@@ -36,9 +37,13 @@ else:
         dev.close()
 ''' % ROOT
 EVEN = tuple(range(4, 42, 2))
-for kern in (() if os.environ.get("CAL_ONLY_PH") else ("pk", "i32")):
+for kern in (() if os.environ.get("CAL_ONLY_PH") or os.environ.get("CAL_ONLY_PKF") else ("pk", "i32")):
     print("# SW kernel", kern, flush=True)
     for C in EVEN:
         subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="sw", CAL_C=str(C), AGX_SW_FORCE_C=str(C), AGX_SW_KERNEL=kern))
+if os.environ.get("CAL_ONLY_PKF"):  # the packed float kernel has every width 4..30
+    for C in range(4, 31):
+        subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="ph", CAL_C=str(C), AGX_PHMM_FORCE_C=str(C)))
+    sys.exit(0)
 for C in EVEN:
     subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, CAL_WHAT="ph", CAL_C=str(C), AGX_PHMM_FORCE_C=str(C)))
