@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kPkThreeWaveWidth = 19;
 
 __device__ __forceinline__ int shr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); } // wave_shr:1
 __device__ __forceinline__ f2 shr1(f2 v)
@@ -35,10 +36,10 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <int C>
-__global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
-                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
-                                                   uint32_t n_waves, const float *__restrict__ lut,
-                                                   const float *__restrict__ lut_mis, double *__restrict__ sums)
+__device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
+                                                  const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                                  uint32_t n_waves, const float *__restrict__ lut,
+                                                  const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
     constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -236,10 +237,30 @@ __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ 
 }
 
 template <int C>
+__global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
+                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                                   uint32_t n_waves, const float *__restrict__ lut,
+                                                   const float *__restrict__ lut_mis, double *__restrict__ sums)
+{
+    phmm_fill_pk_body<C>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+}
+
+// Same fill asked to fit three waves per SIMD (168 VGPRs).  Width 19 -- the tiling of H = 300 -- needs
+// 172 left alone and drops to two waves; the two spilled values are touched once per row.
+template <int C>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+phmm_fill_pk_w3(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
+                const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
+                const float *__restrict__ lut_mis, double *__restrict__ sums)
+{
+    phmm_fill_pk_body<C>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+}
+
+template <int C>
 int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
-    auto k = phmm_fill_pk<C>;
+    auto k = C == kPkThreeWaveWidth ? phmm_fill_pk_w3<C> : phmm_fill_pk<C>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
