@@ -17,13 +17,23 @@
 
 namespace {
 
-constexpr size_t kTabBudget = 20 * 1024; // LDS bytes a wave may spend on several read tables (8 waves/CU fit 160 KiB)
+// LDS bytes a wave may spend on several read tables (8 waves/CU fit 160 KiB); AGX_PHMM_TAB_BUDGET overrides (experiments)
+size_t tab_budget()
+{
+    static const size_t v = [] {
+        const char *e = getenv("AGX_PHMM_TAB_BUDGET");
+        const long n = e ? atol(e) : 0;
+        return n > 0 ? (size_t)n : (size_t)20 * 1024;
+    }();
+    return v;
+}
 constexpr uint32_t kHapSlack = 44;       // zero bytes after every haplotype: any tiling reads in bounds
 
 struct Plan {
     uint32_t out;
     uint32_t read, hap;
     uint32_t R, H;
+    uint32_t th; // the haplotype length the pair is tiled for (packed kernel: the longer one of its lane group)
     uint8_t cls;
     uint8_t G;
 };
@@ -79,12 +89,14 @@ int force_cols_per_lane(const ClassTable &ct)
     return 0;
 }
 
-void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t *G_out)
+// allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice
+void choose_tiling(int precision, uint32_t R, uint32_t H, uint64_t allowed, uint8_t *cls, uint8_t *G_out, double *cost_out)
 {
     const ClassTable ct = class_table(precision);
     int best = -1, bestG = 0;
     double best_cost = 0;
     for (int ci = 0; ci < ct.n; ++ci) {
+        if (!((allowed >> ci) & 1u)) continue;
         const int C = ct.C[ci];
         const int G = (int)((H + C - 1) / C);
         if (G > 64) continue;
@@ -101,6 +113,18 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint8_t *cls, uint8_t 
     }
     *cls = (uint8_t)(best < 0 ? 255 : best);
     *G_out = (uint8_t)bestG;
+    if (cost_out) *cost_out = best_cost;
+}
+
+// AGX_PHMM_MAX_CLASSES: upper bound on the kernel classes a mixed batch may spread over (default 6)
+int max_classes()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_PHMM_MAX_CLASSES");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 6;
+    }();
+    return v;
 }
 
 // Uniform batches (most pairs share one (R, H) shape): the launch lasts ceil(waves / SIMDs)
@@ -309,17 +333,65 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         const ClassTable ct = class_table(kind);
         auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
         std::vector<Plan> gen = gen0;
-        std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
-        for (Plan &p : gen) {
-            const uint32_t key = p.R << 16 | p.H;
-            auto it = memo.find(key);
-            if (it == memo.end()) {
-                uint8_t c = 255, G = 0;
-                choose_tiling(kind, p.R, p.H, &c, &G);
-                it = memo.emplace(key, (uint16_t)(c << 8 | G)).first;
+        // Two haplotypes share a lane group in the packed kernel: within every read's run, order the
+        // haplotypes by length and tile neighbours for the longer of the two, so that partners get the
+        // same class (mixed-length regions would otherwise leave most second slots vacant).
+        for (Plan &p : gen) p.th = p.H;
+        if (slots == 2) {
+            size_t a = 0;
+            while (a < gen.size()) {
+                size_t z = a;
+                while (z < gen.size() && gen[z].read == gen[a].read) ++z;
+                std::stable_sort(gen.begin() + (ptrdiff_t)a, gen.begin() + (ptrdiff_t)z,
+                                 [](const Plan &x, const Plan &y) { return x.H > y.H; });
+                for (size_t k = a; k < z; ++k) gen[k].th = gen[a + ((k - a) & ~(size_t)1)].H; // the pair's longer one
+                a = z;
             }
-            p.cls = (uint8_t)(it->second >> 8);
-            p.G = (uint8_t)(it->second & 0xff);
+        }
+        // Tiling per (R, H) shape.  The per-class cost curve is flat over many widths, and every class
+        // is its own launch: a mixed batch first chooses freely, then keeps the few classes that carry
+        // most of the work and re-tiles the rest among them (a shape no kept class can span keeps its own).
+        std::unordered_map<uint32_t, uint32_t> shapes; // (R << 16 | H) -> count
+        for (const Plan &p : gen) ++shapes[p.R << 16 | p.th];
+        const uint64_t all_classes = ~0ull;
+        std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
+        std::vector<double> class_work((size_t)ct.n, 0.0);
+        for (const auto &sh : shapes) {
+            uint8_t c = 255, G = 0;
+            double cost = 0;
+            choose_tiling(kind, sh.first >> 16, sh.first & 0xffffu, all_classes, &c, &G, &cost);
+            memo.emplace(sh.first, (uint16_t)(c << 8 | G));
+            if (c < ct.n) class_work[c] += cost * sh.second;
+        }
+        {
+            // small batches afford fewer launches: about one class per 8192 wavefronts of work
+            double waves_est = 0;
+            for (const auto &sh : shapes) {
+                const auto it = memo.find(sh.first);
+                if (it != memo.end() && (it->second >> 8) < ct.n) waves_est += (double)sh.second * (it->second & 0xff) / 64.0 / slots;
+            }
+            const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 8192.0));
+            int used = 0;
+            for (double wk : class_work) used += wk > 0;
+            if (used > k_max) {
+                std::vector<int> order((size_t)ct.n);
+                for (int k = 0; k < ct.n; ++k) order[(size_t)k] = k;
+                std::sort(order.begin(), order.end(), [&](int x, int y) { return class_work[(size_t)x] > class_work[(size_t)y]; });
+                uint64_t keep = 0;
+                for (int k = 0; k < k_max; ++k) keep |= 1ull << order[(size_t)k];
+                for (auto &m : memo) {
+                    if ((keep >> (m.second >> 8)) & 1u) continue;
+                    uint8_t c = 255, G = 0;
+                    choose_tiling(kind, m.first >> 16, m.first & 0xffffu, keep, &c, &G, nullptr);
+                    if (c < ct.n) m.second = (uint16_t)(c << 8 | G);
+                }
+            }
+        }
+        for (size_t gi = 0; gi < gen.size(); ++gi) {
+            Plan &p = gen[gi];
+            const uint16_t v = memo[p.R << 16 | p.th];
+            p.cls = (uint8_t)(v >> 8);
+            p.G = (uint8_t)(v & 0xff);
             if (p.cls >= ct.n) {
                 agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", p.read, p.hap, p.H);
                 return AGX_E_LIMIT;
@@ -331,8 +403,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             uint32_t cand = 0;
             int votes = 0;
             for (size_t k = 0; k < 512; ++k) {
-                const Plan &p = gen[k * stride];
-                const uint32_t key = p.R << 16 | p.H;
+                const uint32_t key = gen[k * stride].R << 16 | gen[k * stride].th;
                 if (votes == 0) {
                     cand = key;
                     votes = 1;
@@ -340,21 +411,32 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                     votes += key == cand ? 1 : -1;
             }
             int64_t count = 0;
-            for (const Plan &p : gen)
-                if ((p.R << 16 | p.H) == cand) ++count;
+            for (size_t k = 0; k < gen.size(); ++k)
+                if ((gen[k].R << 16 | gen[k].th) == cand) ++count;
             if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
                 uint8_t c = 255, G = 0;
                 choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count + slots - 1) / slots, 4 * n_cu, &c, &G);
                 if (c < ct.n)
-                    for (Plan &p : gen)
-                        if ((p.R << 16 | p.H) == cand) {
-                            p.cls = c;
-                            p.G = G;
+                    for (size_t k = 0; k < gen.size(); ++k)
+                        if ((gen[k].R << 16 | gen[k].th) == cand) {
+                            gen[k].cls = c;
+                            gen[k].G = G;
                         }
             }
         }
-        // order: class, lanes per group (wide first), then read, haplotype -- haplotypes of one read stay
-        // adjacent (one LDS table).  `gen` is already (read, haplotype)-ordered: one stable counting pass.
+        // order: class, lanes per group (wide first), then long reads first, read, haplotype -- a wave's
+        // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
+        // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
+        {
+            uint32_t max_r = 0;
+            for (const Plan &p : gen) max_r = std::max(max_r, p.R);
+            std::vector<uint32_t> cnt((size_t)max_r + 2, 0);
+            for (const Plan &p : gen) ++cnt[(size_t)(max_r - p.R) + 1];
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            std::vector<Plan> tmp(gen.size());
+            for (const Plan &p : gen) tmp[cnt[(size_t)(max_r - p.R)]++] = p;
+            gen.swap(tmp);
+        }
         std::vector<Plan> plan(gen.size());
         {
             std::vector<uint32_t> cnt((size_t)ct.n * 64 + 1, 0);
@@ -383,7 +465,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                     const Plan &p = plan[i];
                     const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
                     const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                    if (n > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > kTabBudget) break;
+                    if (n > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget()) break;
                     if (p.read != last_read) {
                         put_read(p.read);
                         po.tabs.push_back(PhTab{read_dw[p.read], p.R});

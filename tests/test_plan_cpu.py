@@ -106,3 +106,16 @@ def test_substitution_matrix_plans_and_validation():
     with pytest.raises(agx.AgxError) as e:
         agx.SwBatch(None, b, matrix=bad)
     assert e.value.code == agx.E_LIMIT
+
+
+@pytest.mark.parametrize("prec,floor", [(agx.PHMM_F32_FMA, 0.70), (agx.PHMM_F64, 0.78)])
+def test_mixed_shape_regions_plan_with_few_classes_and_little_padding(prec, floor):
+    """Reads of 50..150 and haplotypes of 280..380 within every region: the planner pairs haplotypes of
+    similar length (packed kernel), keeps the few classes that carry most of the work and fills waves
+    with reads of similar length."""
+    b = synth.phmm_regions(64, 64, 16, 150, 380, seed=83, jitter=100)
+    p = agx.PhmmBatchDev(None, b, prec)
+    i = p.info()
+    p.close()
+    assert i.cells == b.cells() and i.cells / i.padded_cells > floor
+    assert i.n_launches <= (3 if prec == agx.PHMM_F64 else 6)  # a float batch's count includes its double rescue plan

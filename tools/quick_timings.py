@@ -31,3 +31,11 @@ m = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
 b = synth.protein_pairs(65536, 150, 150, seed=2, related_frac=0.25)
 dev = ctx.sw_batch(b, matrix=m); info = dev.info(); ms = timeit(dev, 20)
 print("SW BLOSUM62 65536x~150x150: %.4f ms %.0f GCUPS eff %.3f" % (ms, info.cells/ms/1e6, info.cells/info.padded_cells), flush=True); dev.close()
+# mixed shapes (reads 80..150, haplotypes 200..400 within and across regions)
+p = synth.phmm_regions(256, 64, 16, 150, 400, seed=8, jitter=0)
+parts = [synth.phmm_regions(64, 64, 16, int(R), int(H), seed=80 + k, jitter=int(j)) for k, (R, H, j) in enumerate([(150, 400, 70), (100, 300, 20), (120, 250, 50), (150, 380, 100)])]
+for prec, pn in ((agx.PHMM_F32_FMA, "f32fma"), (agx.PHMM_F64, "f64")):
+    tot_ms = 0.0; tot_cells = 0; tot_pairs = 0
+    for q in parts:
+        dev = ctx.phmm_batch(q, prec); info = dev.info(); ms = timeit(dev, 5)
+        print("PHMM mixed part %s: %.3f ms %.2f Mpairs/s %.0f GCUPS eff %.3f launches %d" % (pn, ms, q.n_pairs/ms/1e3, info.cells/ms/1e6, info.cells/info.padded_cells, info.n_launches), flush=True); dev.close()
