@@ -58,11 +58,13 @@ int force_cols_per_lane()
     return v;
 }
 
-Tiling choose_tiling(bool packed, int lx, int ly)
+// allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice
+Tiling choose_tiling(bool packed, int lx, int ly, uint32_t allowed = ~0u, double *cost_out = nullptr)
 {
     Tiling best{-1, 0};
     double best_cost = 0;
     for (int ci = 0; ci < kSwNumClasses; ++ci) {
+        if (!((allowed >> ci) & 1u)) continue;
         const int C = kSwClasses[ci];
         const int G = (lx + C - 1) / C;
         if (G > 64) continue;
@@ -75,7 +77,19 @@ Tiling choose_tiling(bool packed, int lx, int ly)
             best_cost = c;
         }
     }
+    if (cost_out) *cost_out = best_cost;
     return best;
+}
+
+// AGX_SW_MAX_CLASSES: upper bound on the kernel classes a mixed batch may spread over (default 6)
+int max_classes()
+{
+    static const int v = [] {
+        const char *e = getenv("AGX_SW_MAX_CLASSES");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? n : 6;
+    }();
+    return v;
 }
 
 // Uniform batches (most pairs share one shape, e.g. fixed-length reads): every wave of that shape
@@ -279,6 +293,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         int rc = AGX_OK;
         int64_t bad_pair = -1;
         int64_t cells = 0;
+        double waves = 0;
+        double class_work[sizeof(kSwClasses) / sizeof(kSwClasses[0])] = {};
     };
     std::vector<Worker> wk((size_t)agx_host_threads());
     agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
@@ -307,8 +323,13 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             if (lx > max_short || ly > 0xffffu) rc = AGX_E_LIMIT;
             else if (bad_symbol) rc = AGX_E_SYMBOL;
             else {
-                tl = choose_tiling(packed, (int)lx, (int)ly);
+                double cost = 0;
+                tl = choose_tiling(packed, (int)lx, (int)ly, ~0u, &cost);
                 if (tl.cls < 0 || (matrix && kSwClasses[tl.cls] > 40)) rc = AGX_E_LIMIT; // no wide classes in matrix mode
+                else {
+                    me.class_work[tl.cls] += cost;
+                    me.waves += (double)tl.G / 64.0 / (packed ? 2 : 1);
+                }
             }
             if (rc != AGX_OK) {
                 if (me.rc == AGX_OK) {
@@ -338,6 +359,43 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                               len[2 * p], len[2 * p + 1], max_short);
             return w.rc;
         }
+    // Every class is its own launch and the measured cost curve is flat over many widths: a mixed batch
+    // keeps the classes that carry most of the work -- about one per 2048 wavefronts, at most 6
+    // (tools/sw_mixed_sweep.py: 16384 pairs of 32..512 went from 0.63 to 2.5 TCUPS, 65536 from 2.1 to 3.9) -- and
+    // re-tiles the other pairs among them (a pair no kept class can span keeps its own).
+    {
+        double work[sizeof(kSwClasses) / sizeof(kSwClasses[0])] = {};
+        double waves_est = 0;
+        for (const Worker &w : wk) {
+            waves_est += w.waves;
+            for (int c = 0; c < kSwNumClasses; ++c) work[c] += w.class_work[c];
+        }
+        static const double per_class = [] {
+            const char *e = getenv("AGX_SW_WAVES_PER_CLASS");
+            return e && atof(e) > 0 ? atof(e) : 2048.0;
+        }();
+        const int k_max = std::min(max_classes(), 1 + (int)(waves_est / per_class));
+        int used = 0;
+        for (int c = 0; c < kSwNumClasses; ++c) used += work[c] > 0;
+        if (used > k_max) {
+            int order[sizeof(kSwClasses) / sizeof(kSwClasses[0])];
+            for (int c = 0; c < kSwNumClasses; ++c) order[c] = c;
+            std::sort(order, order + kSwNumClasses, [&](int x, int y) { return work[x] > work[y]; });
+            uint32_t keep = 0;
+            for (int k = 0; k < k_max; ++k) keep |= 1u << order[k];
+            agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t p = lo; p < hi; ++p) {
+                    PairPlan &pp = all[(size_t)p];
+                    if (pp.cls == 255 || ((keep >> pp.cls) & 1u)) continue;
+                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, keep);
+                    if (tl.cls >= 0) {
+                        pp.cls = (uint8_t)tl.cls;
+                        pp.G = (uint8_t)tl.G;
+                    }
+                }
+            });
+        }
+    }
     // dominant shape?  (sampled first, counted only if the sample says so)
     if (n_pairs >= 1024 && n_cu > 0) {
         const size_t stride = (size_t)n_pairs / 512;

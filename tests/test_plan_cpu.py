@@ -28,7 +28,11 @@ def test_mixed_lengths_plan_covers_every_pair_with_little_padding():
     b = synth.sw_pairs(50000, 32, 512, seed=4)
     i = plan_sw(b)
     assert i["cells"] == b.cells() and i["padded"] >= i["cells"]
-    assert i["cells"] / i["padded"] > 0.90 and 1 <= i["launches"] <= 19
+    # a batch this small keeps two classes (one per ~2048 wavefronts of work): fewer, fuller launches
+    # beat the last few points of padding (tools/sw_mixed_sweep.py)
+    assert i["cells"] / i["padded"] > 0.85 and 1 <= i["launches"] <= 6
+    big = plan_sw(synth.sw_pairs(400000, 32, 512, seed=5))
+    assert big["cells"] / big["padded"] > 0.93 and big["launches"] <= 6
 
 
 def test_degenerate_batches_plan():
