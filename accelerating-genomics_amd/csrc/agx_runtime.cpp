@@ -13,6 +13,12 @@ extern "C" void agx_set_error(const char *fmt, ...)
 
 int FanOut::begin()
 {
+    // AGX_FANOUT=0: every launch on the context's stream (experiments)
+    static const bool off = [] {
+        const char *e = getenv("AGX_FANOUT");
+        return e && e[0] == '0';
+    }();
+    if (off) n = 1;
     if (n <= 1) return AGX_OK;
     if (!c->fork) {
         AGX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
