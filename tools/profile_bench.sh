@@ -7,7 +7,7 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
+ARGS="--steps 500 --warmup 50 --no-cpu-baseline $*"   # the default bench run, so durations compare with BENCH json
 echo "== kernel trace" 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py $ARGS > $OUT/kt_bench.json 2> $OUT/kt.err || { echo "kernel-trace run failed"; tail -5 $OUT/kt.err; exit 1; }
 PMCARGS="--steps 4 --warmup 1 --no-cpu-baseline $*"

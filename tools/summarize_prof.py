@@ -18,7 +18,7 @@ def short(name):
 
 
 for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=True):
-    print("## kernel stats (`rocprofv3 --kernel-trace --stats`, bench.py --steps 20 --warmup 3)\n")
+    print("## kernel stats (`rocprofv3 --kernel-trace --stats`, bench.py --steps 500 --warmup 50)\n")
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for r in csv.DictReader(open(f)):
