@@ -640,7 +640,9 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     rc = fan.begin();
     if (rc) return rc;
     int k = 0;
-    for (const ClassLaunch &cl : b->launches) {
+    // widest class first: its waves have the longest rows-times-columns chain, so they should not be the tail
+    for (auto it = b->launches.rbegin(); it != b->launches.rend(); ++it) {
+        const ClassLaunch &cl = *it;
         hipStream_t st = fan.stream(k++);
         const int r = b->matrix
                           ? agx_sw_mat_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,

@@ -15,6 +15,9 @@ Second leg, same JSON line under "pairhmm": BASELINE config 3 -- 65 536 (read, h
 R=100, H=300, fp32 forward (AGX_PHMM_F32_FMA: packed FMA, two haplotypes per lane group) with
 double rescue of underflowing pairs -- in pairs/s.
 
+"config4" / "config5": the two 8-GPU configs of BASELINE.json at one GPU's 1/8 shard (131 072 mixed SW
+pairs; 32 768 PairHMM pairs R=250 H=500 in bit-identical fp64), a tenth of the steps each.
+
 N > 1: every rank owns its own batch of the same shape (independent pairs shard with no
 collective), so scaling is "weak"; torch.distributed (RCCL) is used only for the
 barriers and the max-over-ranks of the timed region.
@@ -41,6 +44,8 @@ sys.path.insert(0, ROOT)
 
 SW_PAIRS, SW_LEN = 65536, 150
 PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H = 64, 64, 16, 100, 300
+C4_PAIRS = 1 << 20                                                  # config 4, all 8 GPUs together
+C5_REGIONS, C5_READS, C5_HAPS, C5_R, C5_H = 512, 32, 16, 250, 500   # config 5 (262 144 pairs), all 8 GPUs together
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # Measured wave64 issue rates on this chip (tools/valu_microbench.hip, profiles/r01_valu_microbench.log):
 # add/xor/mul class ~65 T lane-op/s; max/max3/cndmask/compare/DPP/fma/f64 class ~38 T lane-op/s.
@@ -206,6 +211,29 @@ def main():
     ph_bytes = ph.algorithmic_bytes()  # 808 B/pair
     ph_dev.close()
 
+    # ---------------- the two 8-GPU configs of BASELINE.json, each rank its 1/8 shard (a tenth of the steps)
+    def timed_few(dev):
+        keep = args.steps, args.warmup
+        args.steps, args.warmup = max(10, keep[0] // 10), max(2, keep[1] // 10)
+        try:
+            dt, launch_ms = timed(dev)
+            return dt, launch_ms, args.steps
+        finally:
+            args.steps, args.warmup = keep
+
+    c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
+    c4_dev = ctx.sw_batch(c4)
+    c4_info = c4_dev.info()
+    c4_dt, c4_ms, c4_steps = timed_few(c4_dev)
+    c4_sum = int(c4_dev.scores().astype(np.int64).sum())
+    c4_dev.close()
+    c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
+    c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
+    c5_info = c5_dev.info()
+    c5_dt, c5_ms, c5_steps = timed_few(c5_dev)
+    c5_l, _ = c5_dev.results()
+    c5_dev.close()
+
     if rank != 0:
         if multi:
             dist.barrier()
@@ -247,6 +275,17 @@ def main():
                      "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (4 / VALU_PACKED + 2 / VALU_SLOW) / (ph_launch_ms * 1e-3)},
             "log10_checksum": float(ph_l.sum()),
         },
+        "config4": {
+            "metric": "Smith-Waterman GCUPS, mixed lengths 32-512 (config 4: 1 048 576 pairs over 8 GPUs; %d pairs per GPU here)" % (C4_PAIRS // 8),
+            "value": n_gpus * c4.cells(sentinel=False) * c4_steps / c4_dt / 1e9, "unit": "GCUPS", "steps": c4_steps,
+            "ms_per_step": c4_dt / c4_steps * 1e3, "launch_ms": c4_ms, "launches_per_step": c4_info.n_launches,
+            "useful_cell_fraction": c4_info.cells / max(1, c4_info.padded_cells), "score_checksum": c4_sum},
+        "config5": {
+            "metric": "PairHMM forward pairs/s, fp64 in the reference's operation order (config 5: 262 144 pairs R=250 H=500 over 8 GPUs; %d pairs per GPU here)" % c5.n_pairs,
+            "value": n_gpus * c5.n_pairs * c5_steps / c5_dt, "unit": "pairs/s", "dtype": "f64", "steps": c5_steps,
+            "ms_per_step": c5_dt / c5_steps * 1e3, "launch_ms": c5_ms, "gcups": n_gpus * c5.cells() * c5_steps / c5_dt / 1e9,
+            "launches_per_step": c5_info.n_launches, "useful_cell_fraction": c5_info.cells / max(1, c5_info.padded_cells),
+            "log10_checksum": float(c5_l.sum())},
     }
     if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
         out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
