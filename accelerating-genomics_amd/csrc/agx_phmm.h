@@ -63,10 +63,11 @@ static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic
 // (MI355X, tools/calibrate_classes.py, profiles/r01_calibration*.log); 0 = class not built
-// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.
+// for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.  (Width 32 in double
+// runs the two-waves-per-SIMD build, tools/cal_f64_wide.py.)
 static const double kPhClassCost[3][19] = {
-    {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.220, 0, 0, 0, 0},
-    {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 1.211, 0, 0, 0, 0},
+    {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.017, 0, 0, 0, 0},
+    {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 0.990, 0, 0, 0, 0},
     {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
 };
 

@@ -58,11 +58,11 @@ template <bool FMA> __device__ __forceinline__ float mad(float a, float b, float
 }
 
 template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
-__global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
-                                                const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
-                                                uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
-                                                double *__restrict__ sums,
-                                                double rescue_below, unsigned long long *__restrict__ n_rescued)
+__device__ __forceinline__ void phmm_fill_body(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
+                                               const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                               uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
+                                               double *__restrict__ sums, double rescue_below,
+                                               unsigned long long *__restrict__ n_rescued)
 {
     constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -270,11 +270,33 @@ __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img
 }
 
 template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+__global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
+                                                const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
+                                                uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
+                                                double *__restrict__ sums, double rescue_below,
+                                                unsigned long long *__restrict__ n_rescued)
+{
+    phmm_fill_body<T, C, FMA, RESCUE, PROBS>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
+}
+
+// The same fill asked to fit two waves per SIMD (256 VGPRs).  In double, 32 columns per lane -- the
+// width that tiles H = 500 over 16 lanes, four pairs per wave -- need 267 registers left alone and drop
+// to one wave; with the limit the allocator spills 22 values, all outside the cell loop.
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+phmm_fill_w2(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
+             const PhWave *__restrict__ waves, uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
+             double *__restrict__ sums, double rescue_below, unsigned long long *__restrict__ n_rescued)
+{
+    phmm_fill_body<T, C, FMA, RESCUE, PROBS>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
+}
+
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds,
            hipStream_t s)
 {
-    auto k = phmm_fill<T, C, FMA, RESCUE, PROBS>;
+    auto k = (sizeof(T) == 8 && C == 32) ? phmm_fill_w2<T, C, FMA, RESCUE, PROBS> : phmm_fill<T, C, FMA, RESCUE, PROBS>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
