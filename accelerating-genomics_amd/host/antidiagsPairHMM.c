@@ -8,7 +8,7 @@
  * Built a second time as `pairHMMmatrix` (-DAGX_PHMM_MATRIX_STDOUT): the reference's row-major
  * program pairHMM/pairHMMmatrix.c has the same command line and output file but prints only the
  * `#batch:` lines on stdout (:171 vs its fprintf at :258).
- *   AGX_PHMM_PRECISION = f64 (default; raw sums bit-identical to the reference) | f64fma | f32
+ *   AGX_PHMM_PRECISION = f64 (default; raw sums bit-identical to the reference) | f64fma | f32 | f32fma
  *   AGX_NUM_DEVICES    = n GPUs to shard whole batches over (default 1, 0 = all)
  */
 #include <stdio.h>
@@ -37,6 +37,7 @@ int main(int argc, const char *argv[])
     int precision = AGX_PHMM_F64;
     const char *pe = getenv("AGX_PHMM_PRECISION");
     if (pe && strcmp(pe, "f32") == 0) precision = AGX_PHMM_F32;
+    else if (pe && strcmp(pe, "f32fma") == 0) precision = AGX_PHMM_F32_FMA;
     else if (pe && strcmp(pe, "f64fma") == 0) precision = AGX_PHMM_F64_FMA;
     const char *nd = getenv("AGX_NUM_DEVICES");
     int n_dev = nd ? atoi(nd) : 1;

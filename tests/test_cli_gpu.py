@@ -61,7 +61,7 @@ def test_phmm_cli_precisions_and_truncation(golden_dir, tmp_path):
     exe = os.path.join(BIN, "antidiagsPairHMM")
     src = os.path.join(golden_dir, "phmm_synth.in")
     want = [float(x) for x in open(os.path.join(golden_dir, "phmm_synth.g17.out")).read().split()]
-    for prec, tol in (("f32", 1e-6), ("f64fma", 1e-12)):
+    for prec, tol in (("f32", 1e-6), ("f32fma", 1e-6), ("f64fma", 1e-12)):
         outp = tmp_path / (prec + ".out")
         r = subprocess.run([exe, src, str(outp)], capture_output=True, env=dict(os.environ, AGX_PHMM_PRECISION=prec))
         assert r.returncode == 0
