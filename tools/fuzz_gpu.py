@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: random batch structures through every precision and
+scoring mode against the oracle.  usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+from tests import oracle_api
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+orc = oracle_api.load()
+ctx = agx.Context(0)
+ACGTN = np.frombuffer(b"ACGTN", np.uint8)
+
+
+def relerr(a, b):
+    m = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), m)
+    return float(np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), 1e-300))) if m.any() else 0.0
+
+
+def rand_seq(n, alphabet=ACGTN[:4]):
+    return alphabet[rng.integers(0, alphabet.size, size=n)].tobytes()
+
+
+def phmm_case():
+    regions = []
+    for _ in range(int(rng.integers(1, 6))):
+        hmax = int(rng.choice([8, 40, 120, 400, 1000, 2300]))
+        haps = []
+        for _h in range(int(rng.integers(1, 10))):
+            n = int(rng.integers(0 if rng.random() < 0.05 else 1, hmax + 1))
+            haps.append(rand_seq(n, ACGTN if rng.random() < 0.3 else ACGTN[:4]))
+        reads = []
+        rmax = int(rng.choice([3, 30, 150, 400]))
+        for _r in range(int(rng.integers(1, 12))):
+            R = int(rng.integers(0 if rng.random() < 0.05 else 1, rmax + 1))
+            src = np.frombuffer(max(haps, key=len), np.uint8)
+            if src.size >= R and R and rng.random() < 0.7:
+                st = int(rng.integers(0, src.size - R + 1))
+                bases = src[st:st + R].copy()
+                bases[rng.random(R) < 0.03] = ACGTN[rng.integers(0, 5)]
+                bases = bases.tobytes()
+            else:
+                bases = rand_seq(R, ACGTN)
+            q = lambda lo, hi: (rng.integers(lo, hi, size=R) + 33).astype(np.uint8).tobytes()
+            reads.append((bases, q(2, 42), q(20, 46), q(20, 46), q(5, 20)))
+        regions.append((reads, haps))
+    return synth.phmm_from_regions(regions)
+
+
+def sw_case():
+    seqs = []
+    lmax = int(rng.choice([4, 40, 160, 600, 2700]))
+    for _ in range(int(rng.integers(1, 400))):
+        a = rand_seq(int(rng.integers(0 if rng.random() < 0.03 else 1, lmax + 1)))
+        if rng.random() < 0.5 and len(a) > 2:
+            b = bytearray(a)
+            for _k in range(int(rng.integers(0, 4))):
+                if len(b) < 2:
+                    break
+                pos = int(rng.integers(0, len(b)))
+                if rng.random() < 0.5:
+                    b[pos:pos + 1] = rand_seq(1)
+                else:
+                    del b[pos:pos + int(rng.integers(1, 4))]
+            b = bytes(b) + rand_seq(int(rng.integers(0, 30)))
+        else:
+            b = rand_seq(int(rng.integers(1, lmax + 1)))
+        seqs += [a, b]
+    return synth.sw_from_seqs(seqs)
+
+
+t_end = time.time() + budget
+n_ph = n_sw = 0
+while time.time() < t_end:
+    b = phmm_case()
+    s_ref, l_ref = orc.phmm_batch(b, 0)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64); dev.launch(); l, s = dev.results(); dev.close()
+    assert np.array_equal(s, s_ref), ("f64 sums differ", seed, n_ph)
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), l_ref) <= 1e-12, ("fma", seed, n_ph)
+    for prec in (agx.PHMM_F32, agx.PHMM_F32_FMA):
+        got = ctx.phmm_forward(b, prec)
+        m = np.isfinite(l_ref)
+        assert np.array_equal(np.isfinite(got), m)
+        d = np.abs(got[m] - l_ref[m])
+        # 1e-6 relative on the log10 likelihood or on the likelihood itself (BASELINE north star:
+        # |dlog10| <= 1e-6 / ln 10) -- the first is meaningless where log10 L is close to 0 (reads of 1-2 bases)
+        bad = (d > 1e-6 * np.abs(l_ref[m])) & (d > 1e-6 / np.log(10))
+        assert not bad.any(), ("f32 family", prec, float(d[bad].max()), seed, n_ph)
+    s3, _ = orc.phmm_batch(b, 3)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR); dev.launch(); _, s = dev.results(); dev.close()
+    assert np.array_equal(s, s3), ("gatk", seed, n_ph)
+    n_ph += 1
+    w = sw_case()
+    ref = orc.sw_batch(w)
+    assert np.array_equal(ctx.sw_score(w), ref), ("sw packed/default", seed, n_sw)
+    sc = (int(rng.integers(1, 13)), -int(rng.integers(0, 20)), -int(rng.integers(0, 30)), -int(rng.integers(0, 10)))
+    dev = ctx.sw_batch(w, sc); dev.launch(); got = dev.scores(); dev.close()
+    assert np.array_equal(got, orc.sw_batch_scored(w, sc)), ("sw scored", sc, seed, n_sw)
+    m = agx.SwMatrix.build(b"ACGT", rng.integers(-6, 7, size=(4, 4)).tolist(), -int(rng.integers(0, 12)), -int(rng.integers(0, 4)))
+    for a in range(4):
+        for c in range(a):
+            m.score[a][c] = m.score[c][a]
+    if max(int(x) for x in w.len) <= 2560 if w.n_pairs else True:
+        dev = ctx.sw_batch(w, matrix=m); dev.launch(); got = dev.scores(); dev.close()
+        assert np.array_equal(got, orc.sw_batch_matrix(w, m)), ("sw matrix", seed, n_sw)
+    n_sw += 1
+    if (n_ph % 10) == 0:
+        print("fuzz: %d PairHMM batches, %d SW batches ok" % (n_ph, n_sw), flush=True)
+print("FUZZ_OK seed %d: %d PairHMM batches, %d SW batches" % (seed, n_ph, n_sw))
