@@ -30,8 +30,11 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_trace.csv"), recursive=T
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
         res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"),
-                  r.get("Workgroup_Size"), r.get("Grid_Size"))
+                  r.get("Workgroup_Size_X"), r.get("Grid_Size_X"))
     print("## per-dispatch resources (kernel trace)\n")
+    print("(LDS B is the static allocation only; the PairHMM kernels take their read tables as dynamic LDS: "
+          "32 B x (steps + G - 1) rows per table in the packed kernel -- 4160 B per one-wave workgroup on config 3 -- "
+          "and 33 B per row in the double kernel)\n")
     print("| kernel | VGPR | AGPR | SGPR | LDS B | scratch | wg | grid |\n|---|---|---|---|---|---|---|---|")
     for k, v in res.items():
         print("| %s | %s |" % (k, " | ".join(str(x) for x in v)))
