@@ -40,6 +40,7 @@ struct Plan {
 
 struct ClassLaunch {
     int C = 0;
+    bool all_g16 = true; // every wave of the class has groups of exactly 16 lanes
     uint32_t first_wave = 0, n_waves = 0;
     size_t lds = 0;        // dynamic LDS of the fill in the batch's precision
     size_t lds_rescue = 0; // same tables with double rows (F32 rescue pass)
@@ -516,6 +517,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 w.n_groups = (uint16_t)n;
                 w.n_tabs = (uint16_t)ntabs;
                 w.steps = steps;
+                if (G != 16) cl.all_g16 = false;
                 cl.lds = std::max(cl.lds, tab_bytes(rows_f64, steps + G - 1) * ntabs);
                 cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
                 po.padded += (int64_t)steps * 64 * cl.C * slots;
@@ -722,7 +724,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     auto launch_scalar = [&](const agx_phmm_batch::DevPlan &pl, const ClassLaunch &cl, int mode, hipStream_t st) -> int {
         const bool f64 = mode != 2;
         const size_t lds = mode == 3 && !b->separate_rescue ? cl.lds_rescue : cl.lds; // same records, wider table rows
-        const int r = agx_phmm_launch_class(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)pl.groups.p,
+        const int r = agx_phmm_launch_class(mode, cl.C, cl.all_g16, (const uint32_t *)b->img.p, (const PhGroup *)pl.groups.p,
                                             (const PhTab *)pl.tabs.p, (const PhWave *)pl.waves.p + cl.first_wave, cl.n_waves,
                                             f64 ? lut_d : lut_f, f64 ? mis_for_d : mis_for_f, (double *)b->sums.p,
                                             (double)AGX_PHMM_F32_RESCUE, (unsigned long long *)b->counter.p, lds, st);
@@ -755,7 +757,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         for (const ClassLaunch &cl : b->main.launches) {
             hipStream_t st = fan.stream(k++);
             if (b->packed) {
-                const int r = agx_phmm_pk_launch_class(cl.C, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
                                                        (const PhTab *)b->main.tabs.p,
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
                                                        mis_for_f, (double *)b->sums.p, cl.lds, st);

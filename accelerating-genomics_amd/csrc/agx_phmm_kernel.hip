@@ -46,6 +46,14 @@ __device__ __forceinline__ double shr1(double v)
     return __hiloint2double(shr1i(__double2hiint(v)), shr1i(__double2loint(v)));
 }
 
+// DPP row_shr:1 with bound_ctrl: lane i of every 16-lane row receives lane i-1's v, a row's first lane 0
+__device__ __forceinline__ int rshr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ float rshr1(float v) { return __int_as_float(rshr1i(__float_as_int(v))); }
+__device__ __forceinline__ double rshr1(double v)
+{
+    return __hiloint2double(rshr1i(__double2hiint(v)), rshr1i(__double2loint(v)));
+}
+
 template <bool FMA> __device__ __forceinline__ double mad(double a, double b, double c)
 {
     if constexpr (FMA) return __builtin_fma(a, b, c);
@@ -57,7 +65,9 @@ template <bool FMA> __device__ __forceinline__ float mad(float a, float b, float
     return a * b + c;
 }
 
-template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+// ROW16: every wave of the launch has groups of exactly 16 lanes (uniform batches such as H = 500 in
+// 16 x 32): the groups coincide with the DPP rows, and the row shift's zero fill is the column-0 boundary.
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS, bool ROW16>
 __device__ __forceinline__ void phmm_fill_body(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                                const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
@@ -186,14 +196,23 @@ __device__ __forceinline__ void phmm_fill_body(const uint32_t *__restrict__ img,
             const T mm = 1 - (q_i + q_d);                // mm() (:115-117)
             const T gm = 1 - q_g;
 
-            T lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
-            T acc = 0;
-            if constexpr (CHAIN) acc = shr1(acc_prev);
-            if (start) { // column 0 of rows >= 1 (:168-178)
-                lM = 0;
-                lX = 0;
-                lY = 0;
-                acc = 0;
+            T lM, lX, lY, acc = 0; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
+            if constexpr (ROW16) {
+                lM = rshr1(M[C - 1]);
+                lX = rshr1(X[C - 1]);
+                lY = rshr1(Y[C - 1]);
+                if constexpr (CHAIN) acc = rshr1(acc_prev);
+            } else {
+                lM = shr1(M[C - 1]);
+                lX = shr1(X[C - 1]);
+                lY = shr1(Y[C - 1]);
+                if constexpr (CHAIN) acc = shr1(acc_prev);
+                if (start) {
+                    lM = 0;
+                    lX = 0;
+                    lY = 0;
+                    acc = 0;
+                }
             }
             const T dM0 = pM, dX0 = pX, dY0 = pY;
             pM = lM;
@@ -269,34 +288,34 @@ __device__ __forceinline__ void phmm_fill_body(const uint32_t *__restrict__ img,
     }
 }
 
-template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS, bool ROW16>
 __global__ void __launch_bounds__(64) phmm_fill(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                                 const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                 uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
                                                 double *__restrict__ sums, double rescue_below,
                                                 unsigned long long *__restrict__ n_rescued)
 {
-    phmm_fill_body<T, C, FMA, RESCUE, PROBS>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
+    phmm_fill_body<T, C, FMA, RESCUE, PROBS, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
 }
 
 // The same fill asked to fit two waves per SIMD (256 VGPRs).  In double, 32 columns per lane -- the
 // width that tiles H = 500 over 16 lanes, four pairs per wave -- need 267 registers left alone and drop
 // to one wave; with the limit the allocator spills 22 values, all outside the cell loop.
-template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS, bool ROW16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_w2(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
              const PhWave *__restrict__ waves, uint32_t n_waves, const T *__restrict__ lut, const T *__restrict__ lut_mis,
              double *__restrict__ sums, double rescue_below, unsigned long long *__restrict__ n_rescued)
 {
-    phmm_fill_body<T, C, FMA, RESCUE, PROBS>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
+    phmm_fill_body<T, C, FMA, RESCUE, PROBS, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued);
 }
 
-template <typename T, int C, bool FMA, bool RESCUE, bool PROBS>
+template <typename T, int C, bool FMA, bool RESCUE, bool PROBS, bool ROW16 = false>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds,
            hipStream_t s)
 {
-    auto k = (sizeof(T) == 8 && C == 32) ? phmm_fill_w2<T, C, FMA, RESCUE, PROBS> : phmm_fill<T, C, FMA, RESCUE, PROBS>;
+    auto k = (sizeof(T) == 8 && C == 32) ? phmm_fill_w2<T, C, FMA, RESCUE, PROBS, ROW16> : phmm_fill<T, C, FMA, RESCUE, PROBS, ROW16>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
@@ -307,7 +326,7 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
 }
 
 template <int C>
-int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+int launch_mode(int mode, bool all_g16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
                 uint32_t n_waves, const void *lut, const void *lut_mis, double *sums, double rescue_below,
                 unsigned long long *n_rescued, size_t lds, hipStream_t s)
 {
@@ -318,8 +337,12 @@ int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTa
         return -2;
     } else
     switch (mode) {
-    case 0: return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
-    case 1: return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 0:
+        if (all_g16) return launch<double, C, false, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+        return launch<double, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+    case 1:
+        if (all_g16) return launch<double, C, true, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
+        return launch<double, C, true, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
     case 2: return launch<float, C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
     case 3: return launch<double, C, false, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
     case 4: return launch<double, C, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds, s);
@@ -329,13 +352,13 @@ int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTa
 
 } // namespace
 
-int agx_phmm_launch_class(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
+int agx_phmm_launch_class(int mode, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
                           const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                           double rescue_below, unsigned long long *n_rescued, size_t lds_bytes, hipStream_t s)
 {
     if (n_waves == 0) return 0;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds_bytes, s);
+    case CC: return launch_mode<CC>(mode, all_groups_16, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, rescue_below, n_rescued, lds_bytes, s);
     switch (cols_per_lane) {
         AGX_PH_FOR_EACH_CLASS(AGX_PH_CASE)
     default: return -2;

@@ -32,10 +32,18 @@ __device__ __forceinline__ f2 shr1(f2 v)
 {
     return f2{__int_as_float(shr1i(__float_as_int(v.x))), __int_as_float(shr1i(__float_as_int(v.y)))};
 }
+// DPP row_shr:1 with bound_ctrl: lane i of every 16-lane row receives lane i-1's v, a row's first lane 0
+__device__ __forceinline__ int rshr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ f2 rshr1(f2 v)
+{
+    return f2{__int_as_float(rshr1i(__float_as_int(v.x))), __int_as_float(rshr1i(__float_as_int(v.y)))};
+}
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int C>
+// ROW16: every wave of the launch has groups of exactly 16 lanes (uniform batches such as H = 300 in 16 x 19):
+// the groups coincide with the DPP rows, and the row shift's zero fill is the column-0 boundary.
+template <int C, bool ROW16>
 __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                   uint32_t n_waves, const float *__restrict__ lut,
@@ -149,11 +157,20 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             const f2 mm = splat(ra.z), gm = splat(ra.w);
             const f2 qi = splat(rb.x), qd = splat(rb.y), qg = splat(rb.z);
 
-            f2 lM = shr1(M[C - 1]), lX = shr1(X[C - 1]), lY = shr1(Y[C - 1]);
-            if (start) { // column 0 of rows >= 1 (:168-178)
-                lM = splat(0.f);
-                lX = splat(0.f);
-                lY = splat(0.f);
+            f2 lM, lX, lY; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
+            if constexpr (ROW16) {
+                lM = rshr1(M[C - 1]);
+                lX = rshr1(X[C - 1]);
+                lY = rshr1(Y[C - 1]);
+            } else {
+                lM = shr1(M[C - 1]);
+                lX = shr1(X[C - 1]);
+                lY = shr1(Y[C - 1]);
+                if (start) {
+                    lM = splat(0.f);
+                    lX = splat(0.f);
+                    lY = splat(0.f);
+                }
             }
             const f2 dM0 = pM, dX0 = pX, dY0 = pY;
             pM = lM;
@@ -236,31 +253,31 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     }
 }
 
-template <int C>
+template <int C, bool ROW16>
 __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                    const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                    uint32_t n_waves, const float *__restrict__ lut,
                                                    const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_fill_pk_body<C>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
 // Same fill asked to fit three waves per SIMD (168 VGPRs).  Width 19 -- the tiling of H = 300 -- needs
 // 172 left alone and drops to two waves; the two spilled values are touched once per row.
-template <int C>
+template <int C, bool ROW16>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 phmm_fill_pk_w3(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
                 const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
                 const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_fill_pk_body<C>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
-template <int C>
+template <int C, bool ROW16>
 int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
-    auto k = C == kPkThreeWaveWidth ? phmm_fill_pk_w3<C> : phmm_fill_pk<C>;
+    auto k = C == kPkThreeWaveWidth ? phmm_fill_pk_w3<C, ROW16> : phmm_fill_pk<C, ROW16>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
@@ -272,14 +289,16 @@ int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const
 
 } // namespace
 
-int agx_phmm_pk_launch_class(int cols_per_lane, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
+int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              size_t lds_bytes, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_PH_PK_CASE(CC) \
-    case CC: return launch<CC>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
+    case CC: \
+        return all_groups_16 ? launch<CC, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
+                             : launch<CC, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
         AGX_PH_FOR_EACH_PK_CLASS(AGX_PH_PK_CASE)
 #undef AGX_PH_PK_CASE
     default: return -2;
