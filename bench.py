@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=32768)
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config 4 / config 5 legs (PMC profiling passes)")
     # rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (never for numbers):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="map every rank to device 0")
@@ -221,18 +222,20 @@ def main():
         finally:
             args.steps, args.warmup = keep
 
-    c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
-    c4_dev = ctx.sw_batch(c4)
-    c4_info = c4_dev.info()
-    c4_dt, c4_ms, c4_steps = timed_few(c4_dev)
-    c4_sum = int(c4_dev.scores().astype(np.int64).sum())
-    c4_dev.close()
-    c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
-    c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
-    c5_info = c5_dev.info()
-    c5_dt, c5_ms, c5_steps = timed_few(c5_dev)
-    c5_l, _ = c5_dev.results()
-    c5_dev.close()
+    extra = not args.no_extra_configs
+    if extra:
+        c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
+        c4_dev = ctx.sw_batch(c4)
+        c4_info = c4_dev.info()
+        c4_dt, c4_ms, c4_steps = timed_few(c4_dev)
+        c4_sum = int(c4_dev.scores().astype(np.int64).sum())
+        c4_dev.close()
+        c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
+        c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
+        c5_info = c5_dev.info()
+        c5_dt, c5_ms, c5_steps = timed_few(c5_dev)
+        c5_l, _ = c5_dev.results()
+        c5_dev.close()
 
     if rank != 0:
         if multi:
@@ -275,18 +278,19 @@ def main():
                      "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (4 / VALU_PACKED + 2 / VALU_SLOW) / (ph_launch_ms * 1e-3)},
             "log10_checksum": float(ph_l.sum()),
         },
-        "config4": {
+    }
+    if extra:
+        out["config4"] = {
             "metric": "Smith-Waterman GCUPS, mixed lengths 32-512 (config 4: 1 048 576 pairs over 8 GPUs; %d pairs per GPU here)" % (C4_PAIRS // 8),
             "value": n_gpus * c4.cells(sentinel=False) * c4_steps / c4_dt / 1e9, "unit": "GCUPS", "steps": c4_steps,
             "ms_per_step": c4_dt / c4_steps * 1e3, "launch_ms": c4_ms, "launches_per_step": c4_info.n_launches,
-            "useful_cell_fraction": c4_info.cells / max(1, c4_info.padded_cells), "score_checksum": c4_sum},
-        "config5": {
+            "useful_cell_fraction": c4_info.cells / max(1, c4_info.padded_cells), "score_checksum": c4_sum}
+        out["config5"] = {
             "metric": "PairHMM forward pairs/s, fp64 in the reference's operation order (config 5: 262 144 pairs R=250 H=500 over 8 GPUs; %d pairs per GPU here)" % c5.n_pairs,
             "value": n_gpus * c5.n_pairs * c5_steps / c5_dt, "unit": "pairs/s", "dtype": "f64", "steps": c5_steps,
             "ms_per_step": c5_dt / c5_steps * 1e3, "launch_ms": c5_ms, "gcups": n_gpus * c5.cells() * c5_steps / c5_dt / 1e9,
             "launches_per_step": c5_info.n_launches, "useful_cell_fraction": c5_info.cells / max(1, c5_info.padded_cells),
-            "log10_checksum": float(c5_l.sum())},
-    }
+            "log10_checksum": float(c5_l.sum())}
     if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
         out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
         out["pairhmm"]["cpu_baseline"] = cpu_baseline_phmm(max(1, args.cpu_sample_pairs // (PH_READS * PH_HAPS)))

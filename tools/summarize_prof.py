@@ -26,6 +26,20 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_stats.csv"), recursive=T
               float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     print()
 for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_trace.csv"), recursive=True):
+    # the same trace split by grid size: bench.py launches one kernel class for several workloads
+    # (config 2's 2048-wave launch and config 4's classes share sw_fill_pk<38>), --stats lumps them
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        by[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))].append(
+            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("## kernel durations by launch shape (from the kernel trace; headline launches: sw_fill_pk<38> with 512 "
+          "workgroups = 2048 waves, phmm_fill_pk_w3<19, true> with 8192)\n")
+    print("| kernel | workgroups | calls | avg us | min us | max us |\n|---|---|---|---|---|---|")
+    for (k, wg), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        if k.startswith("__amd"):
+            continue
+        print("| %s | %d | %d | %.2f | %.2f | %.2f |" % (k, wg, len(v), sum(v) / len(v), min(v), max(v)))
+    print()
     res = {}
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
