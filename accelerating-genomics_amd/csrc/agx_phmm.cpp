@@ -866,7 +866,9 @@ int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision,
         agx_set_error("no HIP device is visible (this library has no CPU fallback)");
         return AGX_E_NODEVICE;
     }
-    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    // AGX_MULTI_OVERSUBSCRIBE=1 (tests on a one-GPU box): keep the requested shard count, shard k runs on device k % avail
+    const bool oversub = getenv("AGX_MULTI_OVERSUBSCRIBE") != nullptr && n_devices > 0 && n_devices <= 64;
+    if (n_devices <= 0 || (n_devices > avail && !oversub)) n_devices = avail;
     if (!d || (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off || !log10_lik))) {
         agx_set_error("agx_phmm_forward_multi: bad arguments");
         return AGX_E_ARG;
@@ -909,7 +911,7 @@ int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision,
             sub.region_hap = d->region_hap + lo;
             sub.n_regions = hi - lo;
             agx_ctx *c = nullptr;
-            int rc = agx_ctx_create(k, &c);
+            int rc = agx_ctx_create(k % avail, &c);
             if (!rc) rc = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
             if (rc) errs[k] = agx_last_error();
             agx_ctx_destroy(c);

@@ -717,7 +717,9 @@ int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off,
         agx_set_error("no HIP device is visible (this library has no CPU fallback)");
         return AGX_E_NODEVICE;
     }
-    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    // AGX_MULTI_OVERSUBSCRIBE=1 (tests on a one-GPU box): keep the requested shard count, shard k runs on device k % avail
+    const bool oversub = getenv("AGX_MULTI_OVERSUBSCRIBE") != nullptr && n_devices > 0 && n_devices <= 64;
+    if (n_devices <= 0 || (n_devices > avail && !oversub)) n_devices = avail;
     if (n_pairs < 0 || (n_pairs > 0 && (!off || !len || !scores))) {
         agx_set_error("agx_sw_score_multi: bad arguments");
         return AGX_E_ARG;
@@ -743,7 +745,7 @@ int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off,
             const int64_t lo = cut[d], hi = cut[d + 1];
             if (hi <= lo) return;
             agx_ctx *c = nullptr;
-            int rc = agx_ctx_create(d, &c);
+            int rc = agx_ctx_create(d % avail, &c);
             if (!rc) rc = agx_sw_score(c, bases, off + 2 * lo, len + 2 * lo, hi - lo, scores + lo);
             if (rc) errs[d] = agx_last_error();
             agx_ctx_destroy(c);

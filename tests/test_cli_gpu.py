@@ -106,3 +106,18 @@ def test_pairhmmmatrix_alias(golden_dir, tmp_path):
     assert r.returncode == 0, r.stderr
     assert outp.read_bytes() == open(os.path.join(golden_dir, "phmm_10s.f.out"), "rb").read()
     assert r.stdout == b"".join(b"#batch: %d\n" % k for k in range(1, 9))
+
+
+def test_clis_shard_over_several_devices(golden_dir, tmp_path):
+    """AGX_NUM_DEVICES > 1 (here oversubscribed onto this box's GPU): same bytes out."""
+    env = dict(os.environ, AGX_NUM_DEVICES="3", AGX_MULTI_OVERSUBSCRIBE="1", AGX_CLI_CHUNK_PAIRS="100")
+    r = subprocess.run([os.path.join(BIN, "antidiagonalSmithWaterman"), os.path.join(golden_dir, "sw_mixed.in")],
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    want = open(os.path.join(golden_dir, "sw_mixed.expect"), "rb").read()
+    assert b"".join(l for l in r.stdout.splitlines(keepends=True) if not l.startswith(b"elapsed")) == want
+    outp = tmp_path / "o.out"
+    r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), os.path.join(golden_dir, "phmm_10s.in"), str(outp)],
+                       capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert outp.read_bytes() == open(os.path.join(golden_dir, "phmm_10s.f.out"), "rb").read()

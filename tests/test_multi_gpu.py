@@ -1,0 +1,43 @@
+"""agx_sw_score_multi / agx_phmm_forward_multi (one host thread and context per device,
+contiguous shards balanced by cells, no collective) with more shards than this box has GPUs:
+AGX_MULTI_OVERSUBSCRIBE maps shard k to device k % visible, so the sharding and the aggregation into
+the caller's arrays run here as they would on an 8-GPU node.  Subprocess: the knob is read per call,
+but a clean environment keeps the other tests' contexts out of the picture."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+from tests import oracle_api
+orc = oracle_api.load()
+for n_dev in (2, 3, 8):
+    b = synth.sw_pairs(3001, 1, 300, seed=40 + n_dev, related_frac=0.4)
+    assert np.array_equal(agx.sw_score_multi(b, n_dev), orc.sw_batch(b)), ("sw", n_dev)
+    p = synth.phmm_regions(11, 5, 3, 60, 120, seed=50 + n_dev, jitter=30)
+    s_ref, l_ref = orc.phmm_batch(p, 0)
+    assert np.array_equal(agx.phmm_forward_multi(p, agx.PHMM_F64, n_dev), l_ref), ("phmm", n_dev)
+    got = agx.phmm_forward_multi(p, agx.PHMM_F32_FMA, n_dev)
+    assert np.max(np.abs(got - l_ref) / np.abs(l_ref)) <= 1e-6
+# more shards than pairs / regions, and empty input
+b = synth.sw_pairs(3, 5, 9, seed=1)
+assert np.array_equal(agx.sw_score_multi(b, 8), orc.sw_batch(b))
+p = synth.phmm_regions(2, 2, 2, 10, 20, seed=2)
+assert np.array_equal(agx.phmm_forward_multi(p, agx.PHMM_F64, 8), orc.phmm_batch(p, 0)[1])
+assert agx.sw_score_multi(synth.sw_from_seqs([]), 4).size == 0
+print("MULTI_OK")
+''' % ROOT
+
+
+def test_multi_device_sharding_with_oversubscription():
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, AGX_MULTI_OVERSUBSCRIBE="1"))
+    assert r.returncode == 0 and "MULTI_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
