@@ -31,10 +31,21 @@ bool use_packed_kernel()
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
 // cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
 // by the measured per-cell cost of the class.
+// AGX_SW_TAIL_BETA (experiment): lanes' worth of extra weight on a wave's own duration (steps * C),
+// which favours spreading long pairs over more lanes when the batch is too small to hide tails.
+inline double tail_beta()
+{
+    static const double v = [] {
+        const char *e = getenv("AGX_SW_TAIL_BETA");
+        return e ? atof(e) : 0.0;
+    }();
+    return v;
+}
+
 inline double tiling_cost(bool packed, int ly, int ci, int G)
 {
     const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
-    return (double)(ly + G - 1) * kSwClasses[ci] * (64.0 / (double)(64 / G)) * wgt;
+    return (double)(ly + G - 1) * kSwClasses[ci] * ((64.0 / (double)(64 / G)) * wgt + tail_beta());
 }
 
 // Tuning knob for experiments (not part of the ABI): AGX_SW_MAX_C caps the columns per lane.

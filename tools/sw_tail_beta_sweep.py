@@ -1,0 +1,20 @@
+import sys, os, subprocess
+CHILD = r'''
+import sys; sys.path.insert(0, "/root/repo")
+import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+ctx = agx.Context(0)
+def timeit(dev, reps):
+    dev.launch(); ctx.sync(); best=1e9
+    for _ in range(5):
+        ctx.timer_start()
+        for _ in range(reps): dev.launch()
+        best=min(best, ctx.timer_stop()/reps)
+    return best
+for n in (98304, 131072, 196608, 262144, 393216):
+    b = synth.sw_pairs(n, 32, 512, seed=4)
+    dev = ctx.sw_batch(b); i = dev.info(); ms = timeit(dev, 3)
+    print("  n=%d: %.3f ms %.0f GCUPS eff %.3f launches %d waves %d" % (n, ms, b.cells(False)/ms/1e6, i.cells/i.padded_cells, i.n_launches, i.n_waves), flush=True); dev.close()
+'''
+for beta in (0, 2, 3, 4):
+    print("AGX_SW_TAIL_BETA=%g" % beta, flush=True)
+    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, AGX_SW_TAIL_BETA=str(beta)))
