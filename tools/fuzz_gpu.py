@@ -29,13 +29,13 @@ def rand_seq(n, alphabet=ACGTN[:4]):
 def phmm_case():
     regions = []
     for _ in range(int(rng.integers(1, 6))):
-        hmax = int(rng.choice([8, 40, 120, 400, 1000, 2300]))
+        hmax = int(rng.choice([8, 40, 120, 400, 1000, 2300, 5000], p=[0.15, 0.2, 0.2, 0.2, 0.15, 0.07, 0.03]))
         haps = []
         for _h in range(int(rng.integers(1, 10))):
             n = int(rng.integers(0 if rng.random() < 0.05 else 1, hmax + 1))
             haps.append(rand_seq(n, ACGTN if rng.random() < 0.3 else ACGTN[:4]))
         reads = []
-        rmax = int(rng.choice([3, 30, 150, 400]))
+        rmax = int(rng.choice([3, 30, 150, 400, 1000], p=[0.2, 0.25, 0.3, 0.2, 0.05]))
         for _r in range(int(rng.integers(1, 12))):
             R = int(rng.integers(0 if rng.random() < 0.05 else 1, rmax + 1))
             src = np.frombuffer(max(haps, key=len), np.uint8)
