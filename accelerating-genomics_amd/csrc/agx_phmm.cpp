@@ -286,7 +286,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
 
     // ---- image: every read and haplotype once, shared by all plans of the batch
     std::vector<uint32_t> img;
-    img.resize((64 * 30 + 8) / 4, 0u); // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 30 columns)
+    img.resize((64 * 32 + 8) / 4, 0u); // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 32 columns)
     std::vector<uint32_t> read_dw(d->n_reads, 0xffffffffu), hap_dw(d->n_haps, 0xffffffffu);
     auto put_read = [&](uint32_t r) {
         if (read_dw[r] != 0xffffffffu) return;

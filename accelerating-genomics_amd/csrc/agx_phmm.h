@@ -49,16 +49,17 @@ struct PhWave {
 
 #define AGX_PH_FOR_EACH_CLASS(X) \
     X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18) X(20) X(22) X(24) X(26) X(28) X(30) X(32) X(34) X(36) X(38) X(40)
-// classes of the packed float kernel: six state registers per column, so at most 30 columns
+// classes of the packed float kernel: seven registers per column (six of state, one of symbols); widths
+// 31 and 32 are built for two waves per SIMD like width 32 of the double kernel (257 -> 256 VGPRs)
 #define AGX_PH_FOR_EACH_PK_CLASS(X) \
     X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
-    X(24) X(25) X(26) X(27) X(28) X(29) X(30)
-// (every width: with two haplotypes per group and at most 30 columns, odd widths often tile a
+    X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+// (every width: with two haplotypes per group and at most 32 columns, odd widths often tile a
 // haplotype over all 64 lanes where the even ones leave lanes idle, e.g. H = 300 = 16 lanes x 19)
-static const int kPhPkClasses[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30};
+static const int kPhPkClasses[] = {4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
 static const int kPhPkNumClasses = sizeof(kPhPkClasses) / sizeof(kPhPkClasses[0]);
 // measured for every width (profiles/r01_calibration.log, "packed float kernel, third calibration")
-static const double kPhPkClassCost[] = {1.834, 1.541, 1.454, 1.332, 1.293, 1.220, 1.195, 1.141, 1.137, 1.098, 1.093, 1.083, 1.073, 1.059, 1.063, 1.073, 1.068, 1.044, 1.034, 1.049, 1.034, 1.024, 1.024, 1.029, 1.020, 1.005, 1.000};
+static const double kPhPkClassCost[] = {1.834, 1.541, 1.454, 1.332, 1.293, 1.220, 1.195, 1.141, 1.137, 1.098, 1.093, 1.083, 1.073, 1.059, 1.063, 1.073, 1.068, 1.044, 1.034, 1.049, 1.034, 1.024, 1.024, 1.029, 1.020, 1.005, 1.000, 1.015, 1.005};
 static const int kPhClasses[] = {4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40};
 static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // Measured lane time per padded cell of each class relative to the best one of its arithmetic

@@ -48,7 +48,6 @@ __device__ __forceinline__ double shr1(double v)
 
 // DPP row_shr:1 with bound_ctrl: lane i of every 16-lane row receives lane i-1's v, a row's first lane 0
 __device__ __forceinline__ int rshr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
-__device__ __forceinline__ float rshr1(float v) { return __int_as_float(rshr1i(__float_as_int(v))); }
 __device__ __forceinline__ double rshr1(double v)
 {
     return __hiloint2double(rshr1i(__double2hiint(v)), rshr1i(__double2loint(v)));
@@ -315,7 +314,12 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
            const void *lut, const void *lut_mis, double *sums, double rescue_below, unsigned long long *n_rescued, size_t lds,
            hipStream_t s)
 {
-    auto k = (sizeof(T) == 8 && C == 32) ? phmm_fill_w2<T, C, FMA, RESCUE, PROBS, ROW16> : phmm_fill<T, C, FMA, RESCUE, PROBS, ROW16>;
+    void (*k)(const uint32_t *, const PhGroup *, const PhTab *, const PhWave *, uint32_t, const T *, const T *, double *, double,
+              unsigned long long *);
+    if constexpr (sizeof(T) == 8 && C == 32)
+        k = phmm_fill_w2<T, C, FMA, RESCUE, PROBS, ROW16>;
+    else
+        k = phmm_fill<T, C, FMA, RESCUE, PROBS, ROW16>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;

@@ -273,11 +273,27 @@ phmm_fill_pk_w3(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ g
     phmm_fill_pk_body<C, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
+// ... and two waves per SIMD (256 VGPRs) for widths 31 and 32 (H = 500 in 16 x 32), 257 left alone.
+template <int C, bool ROW16>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+phmm_fill_pk_w2(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
+                const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
+                const float *__restrict__ lut_mis, double *__restrict__ sums)
+{
+    phmm_fill_pk_body<C, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+}
+
 template <int C, bool ROW16>
 int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
-    auto k = C == kPkThreeWaveWidth ? phmm_fill_pk_w3<C, ROW16> : phmm_fill_pk<C, ROW16>;
+    void (*k)(const uint32_t *, const PhGroup2 *, const PhTab *, const PhWave *, uint32_t, const float *, const float *, double *);
+    if constexpr (C == kPkThreeWaveWidth)
+        k = phmm_fill_pk_w3<C, ROW16>;
+    else if constexpr (C > 30)
+        k = phmm_fill_pk_w2<C, ROW16>;
+    else
+        k = phmm_fill_pk<C, ROW16>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;

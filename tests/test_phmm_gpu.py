@@ -106,7 +106,7 @@ def test_shapes_vs_oracle(ctx, oracle, shape):
 
 
 def test_striped_and_single_pass_pairs_in_one_batch(ctx, oracle):
-    """Haplotypes on either side of every span (1920 packed, 2048 f64, 2560 f32) in one region; the
+    """Haplotypes on either side of every span (2048 packed and f64, 2560 f32) in one region; the
     reference's line buffer allows haplotypes up to 5000 (antidiagsPairHMM.c:8,353)."""
     rng = np.random.default_rng(5)
     hap_lens = [300, 1920, 1921, 2048, 2049, 2560, 2561, 3072, 3073, 4608, 4999]
