@@ -31,21 +31,22 @@ bool use_packed_kernel()
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
 // cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
 // by the measured per-cell cost of the class.
-// AGX_SW_TAIL_BETA (experiment): lanes' worth of extra weight on a wave's own duration (steps * C),
-// which favours spreading long pairs over more lanes when the batch is too small to hide tails.
-inline double tail_beta()
+// beta: lanes' worth of extra weight on a wave's own duration (steps * C), which favours spreading long
+// pairs over more lanes.  0 in the throughput regime; the planner raises it for batches whose waves
+// would fill the chip a little more than once (see create_batch).  AGX_SW_TAIL_BETA overrides (experiments).
+inline double tail_beta_override()
 {
     static const double v = [] {
         const char *e = getenv("AGX_SW_TAIL_BETA");
-        return e ? atof(e) : 0.0;
+        return e ? atof(e) : -1.0;
     }();
     return v;
 }
 
-inline double tiling_cost(bool packed, int ly, int ci, int G)
+inline double tiling_cost(bool packed, int ly, int ci, int G, double beta)
 {
     const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
-    return (double)(ly + G - 1) * kSwClasses[ci] * ((64.0 / (double)(64 / G)) * wgt + tail_beta());
+    return (double)(ly + G - 1) * kSwClasses[ci] * ((64.0 / (double)(64 / G)) * wgt + beta);
 }
 
 // Tuning knob for experiments (not part of the ABI): AGX_SW_MAX_C caps the columns per lane.
@@ -70,7 +71,7 @@ int force_cols_per_lane()
 }
 
 // allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice
-Tiling choose_tiling(bool packed, int lx, int ly, uint32_t allowed = ~0u, double *cost_out = nullptr)
+Tiling choose_tiling(bool packed, int lx, int ly, uint32_t allowed = ~0u, double *cost_out = nullptr, double beta = 0.0)
 {
     Tiling best{-1, 0};
     double best_cost = 0;
@@ -82,7 +83,7 @@ Tiling choose_tiling(bool packed, int lx, int ly, uint32_t allowed = ~0u, double
         if (C > max_cols_per_lane() && best.cls >= 0) continue;
         if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
         if ((packed ? kSwPkClassCost[ci] : kSwClassCost[ci]) == 0) continue; // class not built for this kernel
-        const double c = tiling_cost(packed, ly, ci, G);
+        const double c = tiling_cost(packed, ly, ci, G, beta);
         if (best.cls < 0 || c < best_cost || (c == best_cost && C > kSwClasses[best.cls])) {
             best = Tiling{ci, G};
             best_cost = c;
@@ -299,6 +300,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     }
 
     // ---- plan every pair (threads over pairs): validate, orient, choose the lane tiling
+    const double beta0 = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
     std::vector<PairPlan> all((size_t)n_pairs);
     struct Worker {
         int rc = AGX_OK;
@@ -335,7 +337,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             else if (bad_symbol) rc = AGX_E_SYMBOL;
             else {
                 double cost = 0;
-                tl = choose_tiling(packed, (int)lx, (int)ly, ~0u, &cost);
+                tl = choose_tiling(packed, (int)lx, (int)ly, ~0u, &cost, beta0);
                 if (tl.cls < 0 || (matrix && kSwClasses[tl.cls] > 40)) rc = AGX_E_LIMIT; // no wide classes in matrix mode
                 else {
                     me.class_work[tl.cls] += cost;
@@ -370,6 +372,39 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                               len[2 * p], len[2 * p + 1], max_short);
             return w.rc;
         }
+    // Tail regime: when the waves would fill the chip's resident capacity (about 5 per SIMD for this kernel)
+    // between 1.0 and 1.6 times, the second filling is mostly empty and the long waves of the first
+    // decide the launch time.  Re-tile with a term on a wave's own duration (3 lanes' worth): long pairs
+    // spread over more lanes, waves get shorter and more numerous.  Measured on mixed 32..512 batches
+    // (tools/sw_tail_beta_sweep.py): 131 072 pairs 4.2 -> 4.67 TCUPS; outside that band it costs 1-3 %.
+    double beta_used = beta0;
+    if (tail_beta_override() < 0 && n_cu > 0) {
+        double waves_est = 0;
+        for (const Worker &w : wk) waves_est += w.waves;
+        const double fill = waves_est / (5.0 * 4.0 * n_cu);
+        if (fill > 1.0 && fill < 1.6) {
+            beta_used = 3.0;
+            for (Worker &w : wk) {
+                w.waves = 0;
+                for (double &c : w.class_work) c = 0;
+            }
+            agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
+                Worker &me = wk[(size_t)tid];
+                for (int64_t p = lo; p < hi; ++p) {
+                    PairPlan &pp = all[(size_t)p];
+                    if (pp.cls == 255) continue;
+                    double cost = 0;
+                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, ~0u, &cost, 3.0);
+                    if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
+                        pp.cls = (uint8_t)tl.cls;
+                        pp.G = (uint8_t)tl.G;
+                    }
+                    me.class_work[pp.cls] += cost;
+                    me.waves += (double)pp.G / 64.0 / (packed ? 2 : 1);
+                }
+            });
+        }
+    }
     // Every class is its own launch and the measured cost curve is flat over many widths: a mixed batch
     // keeps the classes that carry most of the work -- about one per 2048 wavefronts, at most 6
     // (tools/sw_mixed_sweep.py: 16384 pairs of 32..512 went from 0.63 to 2.5 TCUPS, 65536 from 2.1 to 3.9) -- and
@@ -398,7 +433,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                 for (int64_t p = lo; p < hi; ++p) {
                     PairPlan &pp = all[(size_t)p];
                     if (pp.cls == 255 || ((keep >> pp.cls) & 1u)) continue;
-                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, keep);
+                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, keep, nullptr, beta_used);
                     if (tl.cls >= 0) {
                         pp.cls = (uint8_t)tl.cls;
                         pp.G = (uint8_t)tl.G;

@@ -1,0 +1,17 @@
+import sys; sys.path.insert(0, "/root/repo")
+import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
+ctx = agx.Context(0)
+def timeit(dev, reps):
+    dev.launch(); ctx.sync(); best=1e9
+    for _ in range(5):
+        ctx.timer_start()
+        for _ in range(reps): dev.launch()
+        best=min(best, ctx.timer_stop()/reps)
+    return best
+for n in (65536, 98304, 114688, 131072, 147456, 163840, 196608, 262144, 1048576):
+    b = synth.sw_pairs(n, 32, 512, seed=4)
+    dev = ctx.sw_batch(b); i = dev.info(); ms = timeit(dev, 3)
+    print("  n=%d: %.3f ms %.0f GCUPS eff %.3f launches %d waves %d" % (n, ms, b.cells(False)/ms/1e6, i.cells/i.padded_cells, i.n_launches, i.n_waves), flush=True); dev.close()
+b = synth.sw_pairs(131072, 100, 300, seed=9)
+dev = ctx.sw_batch(b); i = dev.info(); ms = timeit(dev, 3)
+print("  U[100,300] n=131072: %.3f ms %.0f GCUPS waves %d" % (ms, b.cells(False)/ms/1e6, i.n_waves))
