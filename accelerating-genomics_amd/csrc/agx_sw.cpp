@@ -372,17 +372,20 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                               len[2 * p], len[2 * p + 1], max_short);
             return w.rc;
         }
-    // Tail regime: when the waves would fill the chip's resident capacity (about 5 per SIMD for this kernel)
-    // between 1.0 and 1.6 times, the second filling is mostly empty and the long waves of the first
-    // decide the launch time.  Re-tile with a term on a wave's own duration (3 lanes' worth): long pairs
-    // spread over more lanes, waves get shorter and more numerous.  Measured on mixed 32..512 batches
-    // (tools/sw_tail_beta_sweep.py): 131 072 pairs 4.2 -> 4.67 TCUPS; outside that band it costs 1-3 %.
+    // Tail regime: when the planned waves fill the chip's resident capacity (about 5 per SIMD for this
+    // kernel) less than 1.6 times, a launch lasts as long as its longest waves -- alone on their SIMDs
+    // in a small batch, or stranded in a mostly empty second filling.  Such a batch is re-tiled with a
+    // term on a wave's own duration (3 lanes' worth): long pairs spread over more lanes, waves get
+    // shorter and more numerous.  Mixed 32..512 batches (tools/sw_tail_beta_sweep.py,
+    // sw_tail_rule_check.py): 8192 pairs 1.24 -> 2.6 TCUPS, 16 384 2.46 -> 2.9, 131 072 4.15 -> 4.61;
+    // beyond 1.6 fillings the term costs 1-3 % and is left out.  (Uniform batches are re-tiled below
+    // with their own wave-count model.)
     double beta_used = beta0;
     if (tail_beta_override() < 0 && n_cu > 0) {
         double waves_est = 0;
         for (const Worker &w : wk) waves_est += w.waves;
         const double fill = waves_est / (5.0 * 4.0 * n_cu);
-        if (fill > 1.0 && fill < 1.6) {
+        if (fill < 1.6) {
             beta_used = 3.0;
             for (Worker &w : wk) {
                 w.waves = 0;

@@ -8,7 +8,7 @@ def timeit(dev, reps):
         for _ in range(reps): dev.launch()
         best=min(best, ctx.timer_stop()/reps)
     return best
-for n in (65536, 98304, 114688, 131072, 147456, 163840, 196608, 262144, 1048576):
+for n in (2048, 8192, 16384, 32768, 65536, 98304, 131072, 163840, 196608, 262144, 1048576):
     b = synth.sw_pairs(n, 32, 512, seed=4)
     dev = ctx.sw_batch(b); i = dev.info(); ms = timeit(dev, 3)
     print("  n=%d: %.3f ms %.0f GCUPS eff %.3f launches %d waves %d" % (n, ms, b.cells(False)/ms/1e6, i.cells/i.padded_cells, i.n_launches, i.n_waves), flush=True); dev.close()
