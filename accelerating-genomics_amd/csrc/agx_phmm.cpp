@@ -90,8 +90,20 @@ int force_cols_per_lane(const ClassTable &ct)
     return 0;
 }
 
-// allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice
-void choose_tiling(int precision, uint32_t R, uint32_t H, uint64_t allowed, uint8_t *cls, uint8_t *G_out, double *cost_out)
+// AGX_PHMM_TAIL_BETA overrides the planner's tail term (experiments); negative = unset
+double tail_beta_override()
+{
+    static const double v = [] {
+        const char *e = getenv("AGX_PHMM_TAIL_BETA");
+        return e ? atof(e) : -1.0;
+    }();
+    return v;
+}
+
+// allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice;
+// beta: lanes' worth of extra weight on a wave's own duration (steps * C), see make_plan
+void choose_tiling(int precision, uint32_t R, uint32_t H, uint64_t allowed, uint8_t *cls, uint8_t *G_out, double *cost_out,
+                   double beta)
 {
     const ClassTable ct = class_table(precision);
     int best = -1, bestG = 0;
@@ -105,7 +117,7 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint64_t allowed, uint
         if (force_cols_per_lane(ct) && C != force_cols_per_lane(ct)) continue;
         const double wgt = ct.cost[ci];
         if (wgt == 0) continue; // class not built for this arithmetic
-        const double cost = (double)(R + G - 1) * C * (64.0 / (double)(64 / G)) * wgt;
+        const double cost = (double)(R + G - 1) * C * ((64.0 / (double)(64 / G)) * wgt + beta);
         if (best < 0 || cost < best_cost) {
             best = ci;
             bestG = G;
@@ -357,20 +369,35 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         const uint64_t all_classes = ~0ull;
         std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
         std::vector<double> class_work((size_t)ct.n, 0.0);
-        for (const auto &sh : shapes) {
-            uint8_t c = 255, G = 0;
-            double cost = 0;
-            choose_tiling(kind, sh.first >> 16, sh.first & 0xffffu, all_classes, &c, &G, &cost);
-            memo.emplace(sh.first, (uint16_t)(c << 8 | G));
-            if (c < ct.n) class_work[c] += cost * sh.second;
+        double waves_est = 0;
+        auto tile_all = [&](double beta) {
+            memo.clear();
+            std::fill(class_work.begin(), class_work.end(), 0.0);
+            waves_est = 0;
+            for (const auto &sh : shapes) {
+                uint8_t c = 255, G = 0;
+                double cost = 0;
+                choose_tiling(kind, sh.first >> 16, sh.first & 0xffffu, all_classes, &c, &G, &cost, beta);
+                memo.emplace(sh.first, (uint16_t)(c << 8 | G));
+                if (c < ct.n) {
+                    class_work[c] += cost * sh.second;
+                    waves_est += (double)sh.second * G / 64.0 / slots;
+                }
+            }
+        };
+        double beta = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
+        tile_all(beta);
+        // Tail regime (as in the SW planner): a batch whose waves fill the chip's resident capacity (3 waves
+        // per SIMD for the packed kernel, 2 for the others) less than 1.6 times lasts as long as its longest
+        // waves; it is re-tiled with 2 lanes' worth of extra cost on a wave's own duration, which spreads
+        // pairs over more lanes.  Mixed regions (tools/phmm_tail_beta_sweep.py): 2048 pairs +27 % packed /
+        // +35 % double, 16 384 pairs +30 % / +3 %; beyond 1.6 fillings the term costs a few percent.
+        if (tail_beta_override() < 0 && n_cu > 0 && waves_est / ((slots == 2 ? 3.0 : 2.0) * 4.0 * n_cu) < 1.6) {
+            beta = 2.0;
+            tile_all(beta);
         }
         {
             // small batches afford fewer launches: about one class per 8192 wavefronts of work
-            double waves_est = 0;
-            for (const auto &sh : shapes) {
-                const auto it = memo.find(sh.first);
-                if (it != memo.end() && (it->second >> 8) < ct.n) waves_est += (double)sh.second * (it->second & 0xff) / 64.0 / slots;
-            }
             const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 8192.0));
             int used = 0;
             for (double wk : class_work) used += wk > 0;
@@ -383,7 +410,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 for (auto &m : memo) {
                     if ((keep >> (m.second >> 8)) & 1u) continue;
                     uint8_t c = 255, G = 0;
-                    choose_tiling(kind, m.first >> 16, m.first & 0xffffu, keep, &c, &G, nullptr);
+                    choose_tiling(kind, m.first >> 16, m.first & 0xffffu, keep, &c, &G, nullptr, beta);
                     if (c < ct.n) m.second = (uint16_t)(c << 8 | G);
                 }
             }
