@@ -67,9 +67,9 @@ static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.  (Width 32 in double
 // runs the two-waves-per-SIMD build, tools/cal_f64_wide.py.)
 static const double kPhClassCost[3][19] = {
-    {1.647, 1.400, 1.287, 1.233, 1.200, 1.149, 1.127, 1.113, 1.080, 1.049, 1.069, 1.047, 1.033, 1.000, 1.017, 0, 0, 0, 0},
-    {1.724, 1.427, 1.268, 1.216, 1.185, 1.130, 1.104, 1.117, 1.089, 1.081, 1.036, 1.049, 1.026, 1.000, 0.990, 0, 0, 0, 0},
-    {1.887, 1.506, 1.332, 1.253, 1.185, 1.140, 1.098, 1.083, 1.072, 1.049, 1.079, 1.034, 1.023, 1.000, 1.008, 1.000, 1.038, 1.034, 1.030},
+    {1.656, 1.400, 1.307, 1.244, 1.218, 1.173, 1.124, 1.133, 1.109, 1.073, 1.073, 1.053, 1.051, 1.000, 1.011, 0, 0, 0, 0},
+    {1.752, 1.449, 1.330, 1.227, 1.193, 1.174, 1.124, 1.127, 1.108, 1.071, 1.071, 1.050, 1.032, 1.024, 1.000, 0, 0, 0, 0},
+    {1.872, 1.500, 1.346, 1.248, 1.184, 1.158, 1.132, 1.109, 1.090, 1.075, 1.090, 1.068, 1.045, 1.023, 1.011, 1.000, 1.071, 1.056, 1.045},
 };
 
 // bytes of LDS one table row takes: Qr, Qi, Qd, Qg (+ a separate mismatch prior when it is not

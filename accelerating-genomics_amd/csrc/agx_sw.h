@@ -59,9 +59,9 @@ static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
 // Measured lane time per padded cell of each class, relative to the widest one (MI355X,
 // tools/calibrate_classes.py, profiles/r01_calibration*.log): narrow classes amortise the
 // per-step work (DPP shifts, row symbol, loop control) over fewer cells.
-static const double kSwClassCost[] = {1.362, 1.243, 1.174, 1.149, 1.105, 1.083, 1.036, 1.025, 1.029, 1.022, 1.018, 1.011, 1.011, 1.007, 1.004, 1.004, 1.004, 1.004, 1.000, 1.6, 2.2, 4.0};
+static const double kSwClassCost[] = {1.373, 1.250, 1.178, 1.138, 1.112, 1.080, 1.051, 1.033, 1.025, 1.022, 1.014, 1.014, 1.011, 1.007, 1.007, 1.004, 1.004, 1.004, 1.000, 1.6, 2.2, 4.0};
 // same for the packed int16 kernel
-static const double kSwPkClassCost[] = {1.522, 1.348, 1.258, 1.213, 1.163, 1.135, 1.084, 1.079, 1.051, 1.034, 1.022, 1.017, 1.011, 1.017, 1.011, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
+static const double kSwPkClassCost[] = {1.543, 1.358, 1.278, 1.210, 1.173, 1.136, 1.111, 1.086, 1.068, 1.037, 1.025, 1.025, 1.019, 1.012, 1.006, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
 
 // substitution-matrix mode: symbol numbers 1..32 in the image, 0 = padding; the device table is
 // kSwMatDim x kSwMatDim int16 entries score - (gap_open + gap_extend)
