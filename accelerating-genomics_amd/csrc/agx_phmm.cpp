@@ -551,6 +551,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 po.waves.push_back(w);
             }
             cl.n_waves = (uint32_t)po.waves.size() - cl.first_wave;
+            // dispatch order = longest waves first (a wave lasts steps x C): the buckets were filled widest
+            // group first, which leaves narrow groups with long reads for the end of the launch
+            std::stable_sort(po.waves.begin() + cl.first_wave, po.waves.end(),
+                             [](const PhWave &a, const PhWave &b) { return a.steps > b.steps; });
             if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
                 agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
                 return AGX_E_LIMIT;

@@ -386,7 +386,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         for (const Worker &w : wk) waves_est += w.waves;
         const double fill = waves_est / (5.0 * 4.0 * n_cu);
         if (fill < 1.6) {
-            beta_used = 3.0;
+            // the emptier the chip, the more a wave's own duration counts (sweep of 2048 ... 131 072 pairs)
+            beta_used = fill < 0.1 ? 10.0 : fill < 0.4 ? 6.0 : 3.0;
             for (Worker &w : wk) {
                 w.waves = 0;
                 for (double &c : w.class_work) c = 0;
@@ -397,7 +398,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                     PairPlan &pp = all[(size_t)p];
                     if (pp.cls == 255) continue;
                     double cost = 0;
-                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, ~0u, &cost, 3.0);
+                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, ~0u, &cost, beta_used);
                     if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
                         pp.cls = (uint8_t)tl.cls;
                         pp.G = (uint8_t)tl.G;
@@ -557,6 +558,15 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             waves.push_back(w);
         }
         cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
+        // dispatch order = longest waves first (a wave lasts steps x C; C is the class's): the buckets were
+        // filled widest group first, which leaves narrow groups with long rows for the end of the launch
+        static const bool sort_waves = [] {
+            const char *e = getenv("AGX_SW_SORT_WAVES"); // experiment knob: 0 keeps the bucket order
+            return !(e && e[0] == '0');
+        }();
+        if (sort_waves)
+            std::stable_sort(waves.begin() + cl.first_wave, waves.end(),
+                             [](const SwWave &a, const SwWave &b) { return a.steps > b.steps; });
         launches.push_back(cl);
     }
     // group records

@@ -10,11 +10,11 @@ def timeit(dev, reps):
         for _ in range(reps): dev.launch()
         best=min(best, ctx.timer_stop()/reps)
     return best
-for n in (8192, 16384, 32768, 65536, 98304):
+for n in (2048, 8192, 16384, 32768, 65536):
     b = synth.sw_pairs(n, 32, 512, seed=4)
     dev = ctx.sw_batch(b); i = dev.info(); ms = timeit(dev, 3)
     print("  n=%d: %.3f ms %.0f GCUPS eff %.3f launches %d waves %d" % (n, ms, b.cells(False)/ms/1e6, i.cells/i.padded_cells, i.n_launches, i.n_waves), flush=True); dev.close()
 '''
-for beta in (0, 3, 6, 10, 16):
+for beta in (0, 2, 3, 4, 6, 10):
     print("AGX_SW_TAIL_BETA=%g" % beta, flush=True)
     subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, AGX_SW_TAIL_BETA=str(beta)))
