@@ -410,7 +410,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         }
     }
     // Every class is its own launch and the measured cost curve is flat over many widths: a mixed batch
-    // keeps the classes that carry most of the work -- about one per 2048 wavefronts, at most 6
+    // keeps the classes that carry most of the work -- about one per 4096 wavefronts, at most 6
     // (tools/sw_mixed_sweep.py: 16384 pairs of 32..512 went from 0.63 to 2.5 TCUPS, 65536 from 2.1 to 3.9) -- and
     // re-tiles the other pairs among them (a pair no kept class can span keeps its own).
     {
@@ -422,7 +422,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         }
         static const double per_class = [] {
             const char *e = getenv("AGX_SW_WAVES_PER_CLASS");
-            return e && atof(e) > 0 ? atof(e) : 2048.0;
+            return e && atof(e) > 0 ? atof(e) : 4096.0;
         }();
         const int k_max = std::min(max_classes(), 1 + (int)(waves_est / per_class));
         int used = 0;
