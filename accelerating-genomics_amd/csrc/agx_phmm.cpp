@@ -397,8 +397,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             tile_all(beta);
         }
         {
-            // small batches afford fewer launches: about one class per 8192 wavefronts of work
-            const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 8192.0));
+            // small batches afford fewer launches: about one class per 16384 wavefronts of work
+            // (tools/phmm_classes_sweep.py: the count matters little, fewer is never worse by more than 3 %)
+            const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 16384.0));
             int used = 0;
             for (double wk : class_work) used += wk > 0;
             if (used > k_max) {
