@@ -17,16 +17,20 @@ struct Tiling {
     int G;
 };
 
-// AGX_SW_KERNEL=i32 selects the scalar int32 kernel; default is the packed int16 one (two pairs
-// per lane group, agx_sw_pk_kernel.hip).  Scores are identical.
-bool use_packed_kernel()
+// AGX_SW_KERNEL=i32 selects the scalar int32 kernel, pk1 the first packed int16 formulation
+// (agx_sw_pk_kernel.hip); default is the biased packed one (agx_sw_pk2_kernel.hip, two pairs per lane
+// group) whenever its value range allows.  Scores are identical.
+int kernel_choice() // 0 = int32, 1 = packed (signed halves), 2 = packed (biased unsigned halves)
 {
-    static const bool v = [] {
+    static const int v = [] {
         const char *e = getenv("AGX_SW_KERNEL");
-        return !(e && strcmp(e, "i32") == 0);
+        if (e && strcmp(e, "i32") == 0) return 0;
+        if (e && strcmp(e, "pk1") == 0) return 1;
+        return 2;
     }();
     return v;
 }
+bool use_packed_kernel() { return kernel_choice() != 0; }
 
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
 // cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
@@ -151,6 +155,7 @@ struct ClassLaunch {
 struct agx_sw_batch {
     agx_ctx *ctx = nullptr;
     bool packed = false;
+    bool biased = false; // packed batches: the biased formulation (agx_sw_pk2_kernel.hip)
     SwParams prm{};
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
@@ -280,12 +285,24 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     // the packed int16 kernel covers shorter sides up to 64 x 40 columns; one longer pair moves the
     // whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160)
     bool packed = use_packed_kernel() && !matrix; // the matrix lookup exists in the int32 kernel only
+    uint32_t longest_short = 0;
     if (packed)
-        for (int64_t p = 0; p < n_pairs; ++p)
-            if (std::min(len[2 * p], len[2 * p + 1]) > (uint32_t)kSwPackedMaxShort) {
+        for (int64_t p = 0; p < n_pairs; ++p) {
+            const uint32_t sh = std::min(len[2 * p], len[2 * p + 1]);
+            longest_short = std::max(longest_short, sh);
+            if (sh > (uint32_t)kSwPackedMaxShort) {
                 packed = false;
                 break;
             }
+        }
+    // Biased formulation: every stored half must be the pattern of a positive normal half-precision number,
+    // [0x0400, 0x7c00).  Smallest: B - max(|gf| + |ge|, delta); largest: B + (longest shorter side + 1) * match + |gf|.
+    prm.age2 = twice(-prm.ge);
+    prm.agf2 = twice(-prm.gf);
+    const int bias = 0x0400 + std::max(-prm.gf - prm.ge, prm.delta);
+    prm.bias2 = twice(bias);
+    const bool biased = packed && kernel_choice() == 2 &&
+                        (int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00;
     const uint32_t max_short = matrix ? (uint32_t)kSwPackedMaxShort : AGX_SW_MAX_SHORT_LEN; // no wide classes in matrix mode
 
     const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
@@ -640,6 +657,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     b->info.cells = cells;
     b->info.padded_cells = padded;
     b->packed = packed;
+    b->biased = biased;
     b->matrix = matrix != nullptr;
     b->prm = prm;
     b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
@@ -708,7 +726,7 @@ int agx_sw_batch_launch(agx_sw_batch *b)
                                                     (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                     (int32_t *)b->scores.p, (const int16_t *)b->table.p, st)
                           : b->packed
-                          ? agx_sw_pk_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
+                          ? (b->biased ? agx_sw_pk2_launch_class : agx_sw_pk_launch_class)(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
                                                    (int32_t *)b->scores.p, st)
                           : (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(

@@ -23,8 +23,10 @@ struct SwParams {
     int32_t hd;      // match - gf: turns z_diag into H_diag + match
     int32_t delta;   // match - mismatch (> 0)
     int32_t shift;   // packed kernel: symbols are compared as byte << shift, 2^shift >= delta
-    // the same, replicated into both 16-bit halves for the packed kernel
+    // the same, replicated into both 16-bit halves for the packed kernels
     uint32_t ge2, gf2, hd2, delta2;
+    // biased packed kernel (agx_sw_pk2_kernel.hip): |ge|, |gf| and the bias B added to every stored half
+    uint32_t age2, agf2, bias2;
 };
 
 // Packed kernel: one group of G lanes carries two pairs (index 0 = low 16 bits, 1 = high 16 bits
@@ -70,6 +72,8 @@ int agx_sw_mat_launch_class(int cols_per_lane, const SwParams &prm, const uint32
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, const int16_t *table, hipStream_t s);
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
+int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_wide_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
