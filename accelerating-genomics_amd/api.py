@@ -9,22 +9,33 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, "libagx.so"))  # override: kernel experiments only
+# The shipped library reads no environment variable.  The experiment knobs of tools/ exist in the tuning build
+# only (libagx_tuning.so, -DAGX_TUNING): a process that sets one of them gets that library.
+TUNING_KNOBS = ("AGX_SW_KERNEL", "AGX_SW_TAIL_BETA", "AGX_SW_MAX_C", "AGX_SW_FORCE_C", "AGX_SW_MAX_CLASSES", "AGX_SW_WAVES_PER_CLASS",
+                "AGX_SW_SORT_WAVES", "AGX_TRACE_CREATE", "AGX_HOST_THREADS", "AGX_FANOUT", "AGX_PHMM_TAB_BUDGET", "AGX_PHMM_MAX_C",
+                "AGX_PHMM_FORCE_C", "AGX_PHMM_TAIL_BETA", "AGX_PHMM_MAX_CLASSES")
+_DEFAULT_LIB = "libagx_tuning.so" if any(k in os.environ for k in TUNING_KNOBS) else "libagx.so"
+LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, _DEFAULT_LIB))  # override: kernel experiments only
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_SYMBOL, E_LIMIT, E_IO = 0, -1, -2, -3, -4, -5, -6, -7
+OPT_SW_KERNEL = 1
+SW_KERNEL_AUTO, SW_KERNEL_INT32, SW_KERNEL_PACKED_SIGNED, SW_KERNEL_PACKED_BIASED = 0, 1, 2, 3
 PHMM_F64, PHMM_F64_FMA, PHMM_F32, PHMM_F32_FMA = 0, 1, 2, 3
 PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
 
 # every symbol include/agx.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
-    "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_timer_start", "agx_ctx_timer_stop",
+    "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_set_option", "agx_host_alloc", "agx_host_free",
+    "agx_ctx_timer_start", "agx_ctx_timer_stop",
     "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
-    "agx_sw_score", "agx_sw_score_multi",
+    "agx_sw_score", "agx_sw_score_multi", "agx_sw_score_devices", "agx_sw_shard_cuts",
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
-    "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_pairHMM",
+    "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_phmm_forward_devices", "agx_phmm_shard_cuts",
+    "agx_pairHMM",
     "agx_sw_text_read", "agx_sw_text_free", "agx_sw_reader_open", "agx_sw_reader_line_num", "agx_sw_reader_next",
     "agx_sw_reader_done", "agx_sw_reader_close", "agx_phmm_text_read", "agx_phmm_text_free",
+    "agx_phmm_reader_open", "agx_phmm_reader_next", "agx_phmm_reader_done", "agx_phmm_reader_close",
 ]
 
 
@@ -110,6 +121,11 @@ def lib():
         l.agx_ctx_destroy.restype = None
         l.agx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         l.agx_ctx_sync.argtypes = [C.c_void_p]
+        l.agx_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        l.agx_host_alloc.argtypes = [C.c_size_t]
+        l.agx_host_alloc.restype = C.c_void_p
+        l.agx_host_free.argtypes = [C.c_void_p]
+        l.agx_host_free.restype = None
         l.agx_ctx_timer_start.argtypes = [C.c_void_p]
         l.agx_ctx_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.agx_sw_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -125,6 +141,10 @@ def lib():
         l.agx_sw_batch_destroy.restype = None
         l.agx_sw_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         l.agx_sw_score_multi.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.agx_sw_score_devices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        l.agx_sw_shard_cuts.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        l.agx_phmm_forward_devices.argtypes = [C.c_void_p, C.c_int, C.POINTER(PhmmDesc), C.c_int, C.c_void_p]
+        l.agx_phmm_shard_cuts.argtypes = [C.POINTER(PhmmDesc), C.c_int, C.c_void_p]
         l.agx_phmm_batch_create.argtypes = [C.c_void_p, C.POINTER(PhmmDesc), C.c_int, C.POINTER(C.c_void_p)]
         l.agx_phmm_batch_launch.argtypes = [C.c_void_p]
         l.agx_phmm_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -148,6 +168,11 @@ def lib():
         l.agx_phmm_text_read.argtypes = [C.c_char_p, C.POINTER(C.POINTER(PhmmText))]
         l.agx_phmm_text_free.argtypes = [C.POINTER(PhmmText)]
         l.agx_phmm_text_free.restype = None
+        l.agx_phmm_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        l.agx_phmm_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(PhmmText))]
+        l.agx_phmm_reader_done.argtypes = [C.c_void_p]
+        l.agx_phmm_reader_close.argtypes = [C.c_void_p]
+        l.agx_phmm_reader_close.restype = None
         _lib = l
     return _lib
 
@@ -195,6 +220,9 @@ class Context:
 
     def sync(self):
         _check(lib().agx_ctx_sync(self._h))
+
+    def set_option(self, key: int, value: int):
+        _check(lib().agx_ctx_set_option(self._h, key, value))
 
     def timer_start(self):
         _check(lib().agx_ctx_timer_start(self._h))
@@ -317,11 +345,51 @@ def sw_score_multi(b, n_devices: int = 0) -> np.ndarray:
     return out
 
 
+def sw_score_devices(b, devices) -> np.ndarray:
+    """agx_sw_score_devices: shard k of the batch runs on devices[k] (an ordinal may repeat)."""
+    out = np.empty(b.n_pairs, np.int32)
+    dv = np.asarray(devices, np.int32)
+    _check(lib().agx_sw_score_devices(_ptr(dv), dv.size, _ptr(b.bases), _ptr(b.off), _ptr(b.len), b.n_pairs, _ptr(out)))
+    return out
+
+
+def sw_shard_cuts(b, n_shards: int) -> np.ndarray:
+    cut = np.zeros(n_shards + 1, np.int64)
+    _check(lib().agx_sw_shard_cuts(_ptr(b.len), b.n_pairs, n_shards, _ptr(cut)))
+    return cut
+
+
 def phmm_forward_multi(b, precision=PHMM_F64, n_devices: int = 0) -> np.ndarray:
     out = np.empty(b.n_pairs, np.float64)
     d, _keep = phmm_desc(b)
     _check(lib().agx_phmm_forward_multi(n_devices, C.byref(d), precision, _ptr(out)))
     return out
+
+
+def phmm_forward_devices(b, devices, precision=PHMM_F64) -> np.ndarray:
+    out = np.empty(b.n_pairs, np.float64)
+    d, _keep = phmm_desc(b)
+    dv = np.asarray(devices, np.int32)
+    _check(lib().agx_phmm_forward_devices(_ptr(dv), dv.size, C.byref(d), precision, _ptr(out)))
+    return out
+
+
+def phmm_shard_cuts(b, n_shards: int) -> np.ndarray:
+    cut = np.zeros(n_shards + 1, np.uint32)
+    d, _keep = phmm_desc(b)
+    _check(lib().agx_phmm_shard_cuts(C.byref(d), n_shards, _ptr(cut)))
+    return cut
+
+
+def host_array(n: int, dtype) -> np.ndarray:
+    """A numpy array in page-locked memory (agx_host_alloc); never freed explicitly: the few the bench and the
+    tests make live as long as the process."""
+    dt = np.dtype(dtype)
+    p = lib().agx_host_alloc(max(1, n) * dt.itemsize)
+    if not p:
+        raise AgxError(E_NOMEM, lib().agx_last_error().decode(errors="replace"))
+    buf = (C.c_uint8 * (max(1, n) * dt.itemsize)).from_address(p)
+    return np.frombuffer(buf, dtype=dt, count=n)
 
 
 def _sw_text_to_batch(t):
@@ -362,13 +430,10 @@ def read_sw_text_chunks(path: str, max_pairs: int, line_buf: int = 0):
         lib().agx_sw_reader_close(r)
 
 
-def read_phmm_text(path: str):
-    """agx_phmm_text_read -> (synth.PhmmBatch, n_regions_seen, truncated)."""
+def _phmm_text_to_batch(t):
     from . import synth
 
-    t = C.POINTER(PhmmText)()
-    _check(lib().agx_phmm_text_read(path.encode(), C.byref(t)))
-    try:
+    if True:
         d = t.contents.desc
         arr = lambda p, ty, n: (np.ctypeslib.as_array(C.cast(p, C.POINTER(ty)), shape=(n,)).copy() if n else np.zeros(0, ty))
         roff = arr(d.read_off, C.c_uint64, d.n_reads + 1)
@@ -379,5 +444,29 @@ def read_phmm_text(path: str):
                             arr(d.hap_bases, C.c_uint8, nh), hoff, arr(d.region_read, C.c_uint32, d.n_regions + 1),
                             arr(d.region_hap, C.c_uint32, d.n_regions + 1))
         return b, t.contents.n_regions_seen, t.contents.truncated
+
+
+def read_phmm_text(path: str):
+    """agx_phmm_text_read -> (synth.PhmmBatch, n_regions_seen, truncated)."""
+    t = C.POINTER(PhmmText)()
+    _check(lib().agx_phmm_text_read(path.encode(), C.byref(t)))
+    try:
+        return _phmm_text_to_batch(t)
     finally:
         lib().agx_phmm_text_free(t)
+
+
+def read_phmm_text_chunks(path: str, max_pairs: int):
+    """agx_phmm_reader_*: yields (synth.PhmmBatch, n_regions_seen, truncated) per chunk of whole regions."""
+    r = C.c_void_p()
+    _check(lib().agx_phmm_reader_open(path.encode(), C.byref(r)))
+    try:
+        while not lib().agx_phmm_reader_done(r):
+            t = C.POINTER(PhmmText)()
+            _check(lib().agx_phmm_reader_next(r, max_pairs, C.byref(t)))
+            try:
+                yield _phmm_text_to_batch(t)
+            finally:
+                lib().agx_phmm_text_free(t)
+    finally:
+        lib().agx_phmm_reader_close(r)

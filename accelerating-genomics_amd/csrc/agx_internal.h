@@ -1,12 +1,16 @@
-// Internal to libagx.so: context object, error plumbing, device buffer helper.
+// Internal to libagx.so: context object, error plumbing, pooled device / pinned buffers.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <new>
 #include <vector>
 
 #include "../../include/agx.h"
@@ -22,7 +26,41 @@ extern "C" void agx_set_error(const char *fmt, ...) __attribute__((format(printf
         }                                                                                      \
     } while (0)
 
+// Every extern "C" entry point that can allocate runs its body through this: a C caller must never see
+// a C++ exception (std::bad_alloc from a std::vector, std::system_error from a thread).
+#define AGX_GUARD_BEGIN try {
+#define AGX_GUARD_END(fn_name)                                     \
+    }                                                              \
+    catch (const std::bad_alloc &)                                 \
+    {                                                              \
+        agx_set_error("%s: out of host memory", fn_name);          \
+        return AGX_E_NOMEM;                                        \
+    }                                                              \
+    catch (const std::exception &ex_)                              \
+    {                                                              \
+        agx_set_error("%s: %s", fn_name, ex_.what());              \
+        return AGX_E_NOMEM;                                        \
+    }
+
+// Experiment and test knobs (AGX_SW_FORCE_C, AGX_*_TAIL_BETA, AGX_FANOUT, ...) exist only in the tuning
+// build (libagx_tuning.so, -DAGX_TUNING; tools/ and the calibration scripts load that one).  The shipped
+// libagx.so reads no environment variable: it behaves the same in every process.
+static inline const char *agx_tune(const char *name)
+{
+#ifdef AGX_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 constexpr int kAuxStreams = 3;
+
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+};
 
 struct agx_ctx {
     int device = -1;
@@ -30,12 +68,27 @@ struct agx_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 0;
+    // Uploads run on their own stream so that building batch k+1 overlaps the fill of batch k.
+    hipStream_t copy = nullptr;
     // Side streams for batches that need several kernel launches (one per lane-tiling class):
     // the launches are independent, so they are spread over the main stream and these, forked
     // and joined with events -- the tail of one class overlaps the head of the next.
     hipStream_t aux[kAuxStreams] = {nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[kAuxStreams] = {nullptr, nullptr, nullptr};
+    // Batches keep their context alive: agx_ctx_destroy() only drops the creator's reference, the
+    // streams and the pools go when the last batch has been destroyed too (any destroy order is fine).
+    std::atomic<int> refs{1};
+    // Free device / pinned-host blocks kept for the next batch: hipMalloc / hipFree / hipHostMalloc cost
+    // 0.1 .. several ms each and hipFree synchronises the device.
+    std::mutex pool_mu;
+    std::vector<PoolBlock> free_dev, free_pin;
+    size_t cached_dev = 0, cached_pin = 0;
+    // options (agx_ctx_set_option)
+    int opt_sw_kernel = 0;
 };
+
+void agx_ctx_retain(agx_ctx *c);
+void agx_ctx_release(agx_ctx *c); // frees everything when the last reference goes
 
 // Usage: FanOut f(ctx, n_launches); f.begin(); ... launch k on f.stream(k) ...; f.end();
 // Everything is ordered after prior work on ctx->stream and before later work on it.
@@ -49,29 +102,23 @@ struct FanOut {
     int end();
 };
 
-// RAII-less device buffer (freed explicitly so error paths stay simple C-style).
+// Device buffer drawn from its context's pool (freed explicitly so error paths stay simple C-style).
 struct DevBuf {
+    agx_ctx *ctx = nullptr;
     void *p = nullptr;
-    size_t bytes = 0;
-    int alloc(size_t n)
-    {
-        release();
-        if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            agx_set_error("hipMalloc(%zu) -> %s", n, hipGetErrorString(e));
-            return AGX_E_NOMEM;
-        }
-        bytes = n;
-        return AGX_OK;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        bytes = 0;
-    }
+    size_t bytes = 0; // requested size; the block behind it may be larger
+    size_t block = 0;
+    int alloc(agx_ctx *c, size_t n);
+    void release();
+};
+
+// Pinned host staging buffer drawn from the context's pool.
+struct PinBuf {
+    agx_ctx *ctx = nullptr;
+    void *p = nullptr;
+    size_t bytes = 0, block = 0;
+    int alloc(agx_ctx *c, size_t n);
+    void release();
 };
 
 static inline int agx_bind(const agx_ctx *c)
@@ -83,3 +130,8 @@ static inline int agx_bind(const agx_ctx *c)
     AGX_HIP(hipSetDevice(c->device));
     return AGX_OK;
 }
+
+// Process-wide contexts for the entry points that take device ordinals instead of a context
+// (agx_*_devices, agx_*_multi, agx_pairHMM): created on first use, kept until the process ends.
+// slot distinguishes several shards mapped onto the same device.
+int agx_shared_ctx(int device, int slot, agx_ctx **out);

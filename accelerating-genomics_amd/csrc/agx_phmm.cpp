@@ -21,7 +21,7 @@ namespace {
 size_t tab_budget()
 {
     static const size_t v = [] {
-        const char *e = getenv("AGX_PHMM_TAB_BUDGET");
+        const char *e = agx_tune("AGX_PHMM_TAB_BUDGET");
         const long n = e ? atol(e) : 0;
         return n > 0 ? (size_t)n : (size_t)20 * 1024;
     }();
@@ -50,7 +50,7 @@ struct ClassLaunch {
 int max_cols_per_lane()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_PHMM_MAX_C");
+        const char *e = agx_tune("AGX_PHMM_MAX_C");
         const int n = e ? atoi(e) : 0;
         return n >= 4 ? n : kPhClasses[kPhNumClasses - 1];
     }();
@@ -62,7 +62,7 @@ int max_cols_per_lane()
 int force_cols_per_lane_raw()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_PHMM_FORCE_C");
+        const char *e = agx_tune("AGX_PHMM_FORCE_C");
         return e ? atoi(e) : 0;
     }();
     return v;
@@ -94,7 +94,7 @@ int force_cols_per_lane(const ClassTable &ct)
 double tail_beta_override()
 {
     static const double v = [] {
-        const char *e = getenv("AGX_PHMM_TAIL_BETA");
+        const char *e = agx_tune("AGX_PHMM_TAIL_BETA");
         return e ? atof(e) : -1.0;
     }();
     return v;
@@ -133,7 +133,7 @@ void choose_tiling(int precision, uint32_t R, uint32_t H, uint64_t allowed, uint
 int max_classes()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_PHMM_MAX_CLASSES");
+        const char *e = agx_tune("AGX_PHMM_MAX_CLASSES");
         const int n = e ? atoi(e) : 0;
         return n > 0 ? n : 6;
     }();
@@ -184,7 +184,7 @@ void build_lut(bool gatk_prior, double *d, float *f, double *mis_d, float *mis_f
 } // namespace
 
 struct agx_phmm_batch {
-    agx_ctx *ctx = nullptr;
+    agx_ctx *ctx = nullptr; // retained
     int precision = AGX_PHMM_F64;
     bool probs = false; // read tracks are probabilities (pairHMM() seam), not Phred characters
     bool gatk_prior = false;
@@ -234,7 +234,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         return AGX_E_ARG;
     }
 
-    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
+    const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     // ---- enumerate the pairs in output order: region, read, haplotype
@@ -613,6 +613,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     const double t_pack = now();
     // ---- upload
     agx_phmm_batch *b = new agx_phmm_batch();
+    struct Guard { // error paths: free whatever the batch holds
+        agx_phmm_batch *&b;
+        ~Guard()
+        {
+            if (b) agx_phmm_batch_destroy(b);
+        }
+    } guard{b};
+    agx_ctx_retain(ctx);
     b->ctx = ctx;
     b->precision = precision;
     b->probs = probs;
@@ -643,67 +651,76 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }
     if (!ctx) { // planning only
         *out = b;
+        b = nullptr;
         return AGX_OK;
     }
-    double lut_d[256], mis_d[256];
-    float lut_f[256], mis_f[256];
-    build_lut(gatk_prior, lut_d, lut_f, mis_d, mis_f);
-    rc = b->img.alloc(img.size() * 4);
-    if (!rc) rc = b->main.groups.alloc(groups_bytes);
-    if (!rc) rc = b->main.tabs.alloc(pmain.tabs.size() * sizeof(PhTab));
-    if (!rc) rc = b->main.waves.alloc(pmain.waves.size() * sizeof(PhWave));
-    if (!rc && packed) rc = b->rescue.groups.alloc(presc.groups1.size() * sizeof(PhGroup));
-    if (!rc && packed) rc = b->rescue.tabs.alloc(presc.tabs.size() * sizeof(PhTab));
-    if (!rc && packed) rc = b->rescue.waves.alloc(presc.waves.size() * sizeof(PhWave));
-    if (!rc && !pstripe.waves.empty()) {
-        rc = b->stripe.groups.alloc(pstripe.groups1.size() * sizeof(PhGroup));
-        if (!rc) rc = b->stripe.tabs.alloc(pstripe.tabs.size() * sizeof(PhTab));
-        if (!rc) rc = b->stripe.waves.alloc(pstripe.waves.size() * sizeof(PhWave));
-        if (!rc) rc = b->stripe_scratch.alloc((size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
-    }
-    if (!rc) rc = b->sums.alloc(((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
-    if (!rc) rc = b->lut.alloc(2 * (sizeof lut_d + sizeof lut_f)); // [lut_d][lut_f][mis_d][mis_f]
-    if (!rc) rc = b->counter.alloc(sizeof(unsigned long long));
-    if (rc) {
-        agx_phmm_batch_destroy(b);
-        return rc;
-    }
-    hipError_t e = hipSuccess;
-    auto up = [&](DevBuf &dst, const void *src, size_t n) {
-        if (e == hipSuccess && n) e = hipMemcpy(dst.p, src, n, hipMemcpyHostToDevice);
+    // Everything goes through one pinned staging block and the context's copy stream: one DMA per array,
+    // one synchronisation at the end (create is blocking by contract).
+    struct Piece {
+        DevBuf *dst;
+        const void *src;
+        size_t bytes;
     };
-    up(b->img, img.data(), img.size() * 4);
-    up(b->main.groups, packed ? (const void *)pmain.groups2.data() : (const void *)pmain.groups1.data(), groups_bytes);
-    up(b->main.tabs, pmain.tabs.data(), pmain.tabs.size() * sizeof(PhTab));
-    up(b->main.waves, pmain.waves.data(), pmain.waves.size() * sizeof(PhWave));
+    struct Lut {
+        double d[256];
+        float f[256];
+        double mis_d[256];
+        float mis_f[256];
+    } lut; // layout the launch code relies on: [lut_d][lut_f][mis_d][mis_f]
+    build_lut(gatk_prior, lut.d, lut.f, lut.mis_d, lut.mis_f);
+    std::vector<Piece> pieces;
+    pieces.push_back(Piece{&b->img, img.data(), img.size() * 4});
+    pieces.push_back(Piece{&b->main.groups, packed ? (const void *)pmain.groups2.data() : (const void *)pmain.groups1.data(), groups_bytes});
+    pieces.push_back(Piece{&b->main.tabs, pmain.tabs.data(), pmain.tabs.size() * sizeof(PhTab)});
+    pieces.push_back(Piece{&b->main.waves, pmain.waves.data(), pmain.waves.size() * sizeof(PhWave)});
     if (packed) {
-        up(b->rescue.groups, presc.groups1.data(), presc.groups1.size() * sizeof(PhGroup));
-        up(b->rescue.tabs, presc.tabs.data(), presc.tabs.size() * sizeof(PhTab));
-        up(b->rescue.waves, presc.waves.data(), presc.waves.size() * sizeof(PhWave));
+        pieces.push_back(Piece{&b->rescue.groups, presc.groups1.data(), presc.groups1.size() * sizeof(PhGroup)});
+        pieces.push_back(Piece{&b->rescue.tabs, presc.tabs.data(), presc.tabs.size() * sizeof(PhTab)});
+        pieces.push_back(Piece{&b->rescue.waves, presc.waves.data(), presc.waves.size() * sizeof(PhWave)});
     }
     if (!pstripe.waves.empty()) {
-        up(b->stripe.groups, pstripe.groups1.data(), pstripe.groups1.size() * sizeof(PhGroup));
-        up(b->stripe.tabs, pstripe.tabs.data(), pstripe.tabs.size() * sizeof(PhTab));
-        up(b->stripe.waves, pstripe.waves.data(), pstripe.waves.size() * sizeof(PhWave));
-        if (e == hipSuccess) e = hipMemset(b->stripe_scratch.p, 0, b->stripe_scratch.bytes);
+        pieces.push_back(Piece{&b->stripe.groups, pstripe.groups1.data(), pstripe.groups1.size() * sizeof(PhGroup)});
+        pieces.push_back(Piece{&b->stripe.tabs, pstripe.tabs.data(), pstripe.tabs.size() * sizeof(PhTab)});
+        pieces.push_back(Piece{&b->stripe.waves, pstripe.waves.data(), pstripe.waves.size() * sizeof(PhWave)});
     }
-    up(b->lut, lut_d, sizeof lut_d);
-    if (e == hipSuccess) e = hipMemcpy((char *)b->lut.p + sizeof lut_d, lut_f, sizeof lut_f, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy((char *)b->lut.p + sizeof lut_d + sizeof lut_f, mis_d, sizeof mis_d, hipMemcpyHostToDevice);
-    if (e == hipSuccess)
-        e = hipMemcpy((char *)b->lut.p + 2 * sizeof lut_d + sizeof lut_f, mis_f, sizeof mis_f, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(b->sums.p, 0, b->sums.bytes); // degenerate pairs keep sum 0
-    if (e == hipSuccess) e = hipMemset(b->counter.p, 0, b->counter.bytes);
+    pieces.push_back(Piece{&b->lut, &lut, sizeof lut});
+    size_t stage_bytes = 0;
+    for (const Piece &pc : pieces) stage_bytes += (pc.bytes + 255) & ~(size_t)255;
+    PinBuf stage;
+    struct StageGuard {
+        PinBuf &s;
+        ~StageGuard() { s.release(); }
+    } stage_guard{stage};
+    rc = stage.alloc(ctx, stage_bytes);
+    for (const Piece &pc : pieces)
+        if (!rc) rc = pc.dst->alloc(ctx, pc.bytes);
+    if (!rc && !pstripe.waves.empty()) rc = b->stripe_scratch.alloc(ctx, (size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
+    if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
+    if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
+    if (rc) return rc;
+    hipStream_t cs = ctx->copy;
+    hipError_t e = hipSuccess;
+    {
+        size_t at = 0;
+        for (const Piece &pc : pieces) {
+            if (pc.bytes) memcpy((char *)stage.p + at, pc.src, pc.bytes);
+            if (e == hipSuccess && pc.bytes) e = hipMemcpyAsync(pc.dst->p, (char *)stage.p + at, pc.bytes, hipMemcpyHostToDevice, cs);
+            at += (pc.bytes + 255) & ~(size_t)255;
+        }
+    }
+    if (e == hipSuccess && !pstripe.waves.empty()) e = hipMemsetAsync(b->stripe_scratch.p, 0, b->stripe_scratch.bytes, cs);
+    if (e == hipSuccess) e = hipMemsetAsync(b->sums.p, 0, b->sums.bytes, cs); // degenerate pairs keep sum 0
+    if (e == hipSuccess) e = hipMemsetAsync(b->counter.p, 0, b->counter.bytes, cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
     if (e != hipSuccess) {
         agx_set_error("agx_phmm_batch_create: upload -> %s", hipGetErrorString(e));
-        agx_phmm_batch_destroy(b);
         return AGX_E_HIP;
     }
     if (trace)
         fprintf(stderr, "[agx_phmm_batch_create] %lld pairs: plan+order %.2f ms, waves+pack %.2f ms, alloc+H2D %.2f ms (%.1f MB)\n",
                 (long long)n_pairs, t_plan - t_begin, t_pack - t_plan, now() - t_pack, img.size() * 4 / 1e6);
     *out = b;
+    b = nullptr;
     return AGX_OK;
 }
 
@@ -725,12 +742,15 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     b->sums.release();
     b->lut.release();
     b->counter.release();
+    agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
     delete b;
 }
 
 int agx_phmm_batch_create(agx_ctx *ctx, const agx_phmm_desc *d, int precision, agx_phmm_batch **out)
 {
+    AGX_GUARD_BEGIN
     return create_batch(ctx, d, nullptr, precision, out);
+    AGX_GUARD_END("agx_phmm_batch_create")
 }
 
 int agx_phmm_batch_launch(agx_phmm_batch *b)
@@ -826,6 +846,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
 
 int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum)
 {
+    AGX_GUARD_BEGIN
     if (!b || (!log10_lik && b->n_pairs)) {
         agx_set_error("agx_phmm_batch_results: null argument");
         return AGX_E_ARG;
@@ -836,17 +857,22 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
+    // through pinned staging on the launch stream: the DMA queues right behind the last kernel
+    const size_t sum_bytes = (size_t)b->n_pairs * sizeof(double);
+    PinBuf stage;
+    rc = stage.alloc(b->ctx, sum_bytes + sizeof(unsigned long long));
+    if (rc) return rc;
+    struct StageGuard {
+        PinBuf &s;
+        ~StageGuard() { s.release(); }
+    } stage_guard{stage};
+    if (b->n_pairs) AGX_HIP(hipMemcpyAsync(stage.p, b->sums.p, sum_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    AGX_HIP(hipMemcpyAsync((char *)stage.p + sum_bytes, b->counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->ctx->stream));
     AGX_HIP(hipStreamSynchronize(b->ctx->stream));
-    std::vector<double> tmp;
-    double *s = raw_sum;
-    if (!s) {
-        tmp.resize((size_t)b->n_pairs);
-        s = tmp.data();
-    }
-    if (b->n_pairs) AGX_HIP(hipMemcpy(s, b->sums.p, (size_t)b->n_pairs * sizeof(double), hipMemcpyDeviceToHost));
     unsigned long long nres = 0;
-    AGX_HIP(hipMemcpy(&nres, b->counter.p, sizeof nres, hipMemcpyDeviceToHost));
+    memcpy(&nres, (char *)stage.p + sum_bytes, sizeof nres);
     b->info.n_rescued = (int64_t)nres;
+    double *s = (double *)stage.p; // sign fix-ups of the float modes happen in place, then raw_sum (if wanted) gets a copy
     // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
@@ -867,7 +893,9 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
             }
         }
     });
+    if (raw_sum && b->n_pairs) memcpy(raw_sum, s, sum_bytes);
     return AGX_OK;
+    AGX_GUARD_END("agx_phmm_batch_results")
 }
 
 int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info)
@@ -891,24 +919,16 @@ int agx_phmm_forward(agx_ctx *ctx, const agx_phmm_desc *d, int precision, double
     return rc;
 }
 
-int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik)
+int agx_phmm_shard_cuts(const agx_phmm_desc *d, int n_shards, uint32_t *cut)
 {
-    const int avail = agx_device_count();
-    if (avail <= 0) {
-        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
-        return AGX_E_NODEVICE;
-    }
-    // AGX_MULTI_OVERSUBSCRIBE=1 (tests on a one-GPU box): keep the requested shard count, shard k runs on device k % avail
-    const bool oversub = getenv("AGX_MULTI_OVERSUBSCRIBE") != nullptr && n_devices > 0 && n_devices <= 64;
-    if (n_devices <= 0 || (n_devices > avail && !oversub)) n_devices = avail;
-    if (!d || (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off || !log10_lik))) {
-        agx_set_error("agx_phmm_forward_multi: bad arguments");
+    if (!d || n_shards < 1 || !cut || (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off))) {
+        agx_set_error("agx_phmm_shard_cuts: bad arguments");
         return AGX_E_ARG;
     }
     // whole regions stay together; contiguous shards balanced by cells
     const uint32_t ng = d->n_regions;
-    std::vector<double> cost(ng);
-    std::vector<int64_t> first_out(ng + 1, 0);
+    for (int k = 0; k <= n_shards; ++k) cut[k] = ng;
+    cut[0] = 0;
     double total = 0;
     for (uint32_t g = 0; g < ng; ++g) {
         const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
@@ -916,47 +936,95 @@ int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision,
             agx_set_error("region %u: ranges out of order or out of bounds", g);
             return AGX_E_ARG;
         }
-        const double rb = (double)(d->read_off[r1] - d->read_off[r0]), hb = (double)(d->hap_off[h1] - d->hap_off[h0]);
-        cost[g] = rb * hb + 1.0;
-        total += cost[g];
-        first_out[g + 1] = first_out[g] + (int64_t)(r1 - r0) * (h1 - h0);
+        total += (double)(d->read_off[r1] - d->read_off[r0]) * (double)(d->hap_off[h1] - d->hap_off[h0]) + 1.0;
     }
-    std::vector<uint32_t> cut(n_devices + 1, ng);
-    cut[0] = 0;
-    {
-        double acc = 0;
-        int k = 1;
-        for (uint32_t g = 0; g < ng && k < n_devices; ++g) {
-            acc += cost[g];
-            while (k < n_devices && acc >= total * k / n_devices) cut[k++] = g + 1;
+    double acc = 0;
+    int k = 1;
+    for (uint32_t g = 0; g < ng && k < n_shards; ++g) {
+        const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+        acc += (double)(d->read_off[r1] - d->read_off[r0]) * (double)(d->hap_off[h1] - d->hap_off[h0]) + 1.0;
+        while (k < n_shards && acc >= total * k / n_shards) cut[k++] = g + 1;
+    }
+    return AGX_OK;
+}
+
+int agx_phmm_forward_devices(const int *devices, int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik)
+{
+    AGX_GUARD_BEGIN
+    const int avail = agx_device_count();
+    if (avail <= 0) {
+        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
+        return AGX_E_NODEVICE;
+    }
+    if (!devices || n_devices < 1 || n_devices > 1024 || !d ||
+        (d->n_regions && (!d->region_read || !d->region_hap || !d->read_off || !d->hap_off || !log10_lik))) {
+        agx_set_error("agx_phmm_forward_devices: bad arguments");
+        return AGX_E_ARG;
+    }
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= avail) {
+            agx_set_error("agx_phmm_forward_devices: device %d out of range [0,%d)", devices[k], avail);
+            return AGX_E_NODEVICE;
         }
-    }
-    std::vector<int> rcs(n_devices, AGX_OK);
-    std::vector<std::string> errs(n_devices);
-    std::vector<std::thread> th;
-    for (int k = 0; k < n_devices; ++k) {
-        th.emplace_back([&, k]() {
-            const uint32_t lo = cut[k], hi = cut[k + 1];
-            if (hi <= lo) return;
+    std::vector<uint32_t> cut((size_t)n_devices + 1);
+    int rc = agx_phmm_shard_cuts(d, n_devices, cut.data());
+    if (rc) return rc;
+    const uint32_t ng = d->n_regions;
+    std::vector<int64_t> first_out((size_t)ng + 1, 0);
+    for (uint32_t g = 0; g < ng; ++g)
+        first_out[g + 1] = first_out[g] + (int64_t)(d->region_read[g + 1] - d->region_read[g]) * (d->region_hap[g + 1] - d->region_hap[g]);
+    std::vector<int> rcs((size_t)n_devices, AGX_OK), slot((size_t)n_devices, 0);
+    for (int k = 0; k < n_devices; ++k) // shards sharing a device get contexts of their own
+        for (int j = 0; j < k; ++j) slot[(size_t)k] += devices[j] == devices[k];
+    std::vector<std::string> errs((size_t)n_devices);
+    auto shard = [&](int k) {
+        const uint32_t lo = cut[(size_t)k], hi = cut[(size_t)k + 1];
+        if (hi <= lo) return;
+        int r;
+        try {
             agx_phmm_desc sub = *d;
             sub.region_read = d->region_read + lo; // absolute read/hap indices stay valid
             sub.region_hap = d->region_hap + lo;
             sub.n_regions = hi - lo;
             agx_ctx *c = nullptr;
-            int rc = agx_ctx_create(k % avail, &c);
-            if (!rc) rc = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
-            if (rc) errs[k] = agx_last_error();
-            agx_ctx_destroy(c);
-            rcs[k] = rc;
-        });
+            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c); // created once per process: pools stay warm
+            if (!r) r = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
+        } catch (const std::exception &ex) {
+            agx_set_error("shard %d: %s", k, ex.what());
+            r = AGX_E_NOMEM;
+        }
+        if (r) errs[(size_t)k] = agx_last_error();
+        rcs[(size_t)k] = r;
+    };
+    if (n_devices == 1)
+        shard(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_devices; ++k) th.emplace_back(shard, k);
+        shard(0);
+        for (auto &t : th) t.join();
     }
-    for (auto &t : th) t.join();
     for (int k = 0; k < n_devices; ++k)
-        if (rcs[k]) {
-            agx_set_error("device %d: %s", k, errs[k].c_str());
-            return rcs[k];
+        if (rcs[(size_t)k]) {
+            agx_set_error("device %d: %s", devices[k], errs[(size_t)k].c_str());
+            return rcs[(size_t)k];
         }
     return AGX_OK;
+    AGX_GUARD_END("agx_phmm_forward_devices")
+}
+
+int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik)
+{
+    const int avail = agx_device_count();
+    if (avail <= 0) {
+        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
+        return AGX_E_NODEVICE;
+    }
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    n_devices = std::min(n_devices, 1024);
+    int devs[1024];
+    for (int k = 0; k < n_devices; ++k) devs[k] = k;
+    return agx_phmm_forward_devices(devs, n_devices, d, precision, log10_lik);
 }
 
 void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, char *H, int read_len, int haplotype_len,
@@ -966,7 +1034,7 @@ void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, c
     (void)X;
     (void)Y; // the reference's rolling anti-diagonal scratch (antidiagsPairHMM.c:452-455): unused here
     static std::mutex mu;
-    static agx_ctx *ctx = nullptr;
+    agx_ctx *ctx = nullptr;
     std::lock_guard<std::mutex> lock(mu);
     if (!likelihood) return;
     *likelihood = NAN;
@@ -974,7 +1042,8 @@ void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, c
         agx_set_error("agx_pairHMM: bad arguments");
         return;
     }
-    if (!ctx && agx_ctx_create(0, &ctx) != AGX_OK) return;
+    try {
+    if (agx_shared_ctx(0, 0, &ctx) != AGX_OK) return; // process-wide, created on first use
     const uint64_t roff[2] = {0, (uint64_t)read_len}, hoff[2] = {0, (uint64_t)haplotype_len};
     const uint32_t reg[2] = {0, 1};
     agx_phmm_desc d{};
@@ -993,6 +1062,9 @@ void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, c
     double v = NAN;
     if (agx_phmm_batch_launch(b) == AGX_OK && agx_phmm_batch_results(b, &v, nullptr) == AGX_OK) *likelihood = v;
     agx_phmm_batch_destroy(b);
+    } catch (const std::exception &ex) {
+        agx_set_error("agx_pairHMM: %s", ex.what());
+    }
 }
 
 } // extern "C"

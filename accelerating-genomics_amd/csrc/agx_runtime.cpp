@@ -1,5 +1,11 @@
-// Context, error text and stopwatch of the C-ABI (include/agx.h, "runtime" section).
+// Context, error text, stopwatch, buffer pools and the host thread pool of the C-ABI
+// (include/agx.h, "runtime" section).
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
 #include "agx_internal.h"
+#include "agx_parallel.h"
 
 static thread_local char g_err[512] = "";
 
@@ -11,11 +17,281 @@ extern "C" void agx_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ------------------------------------------------------------------ host thread pool
+
+namespace {
+
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> jobs;
+    std::atomic<int> pending{0}; // jobs.size(), readable without the lock
+    std::vector<std::thread> workers;
+    bool stop = false;
+    int parts = 1;
+
+    Pool()
+    {
+        // 8 parts are plenty for byte shuffling and counting sorts; AGX_HOST_THREADS (tuning build) overrides
+        const char *e = agx_tune("AGX_HOST_THREADS");
+        int n = e ? atoi(e) : 0;
+        if (n <= 0) n = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        parts = n;
+        try {
+            for (int k = 0; k + 1 < n; ++k) workers.emplace_back([this] { loop(); });
+        } catch (...) {
+            parts = (int)workers.size() + 1; // fewer threads than wanted is fine
+        }
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : workers) t.join();
+    }
+    void loop()
+    {
+        // A planner is a dozen short parallel regions back to back: a worker that has just finished a job
+        // polls for the next one for a few tens of microseconds before it sleeps on the condition variable
+        // (waking a sleeper costs about as much as a region of a 65 536-pair batch).
+        int spin = 0;
+        for (;;) {
+            std::function<void()> job;
+            if (pending.load(std::memory_order_acquire) > 0 || spin == 0) {
+                std::unique_lock<std::mutex> l(mu);
+                if (spin == 0) cv.wait(l, [this] { return stop || !jobs.empty(); });
+                if (jobs.empty()) {
+                    if (stop) return;
+                } else {
+                    job = std::move(jobs.front());
+                    jobs.pop_front();
+                    pending.fetch_sub(1, std::memory_order_release);
+                }
+            }
+            if (job) {
+                job();
+                spin = 4000;
+            } else if (spin > 0) {
+                --spin;
+                __builtin_ia32_pause();
+            }
+        }
+    }
+};
+
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+
+} // namespace
+
+int agx_host_threads() { return pool().parts; }
+
+void agx_pool_run(int parts, const std::function<void(int)> &task)
+{
+    if (parts <= 1) {
+        task(0);
+        return;
+    }
+    Pool &p = pool();
+    struct Sync {
+        std::mutex mu;
+        std::condition_variable cv;
+        int left;
+        std::exception_ptr err;
+    } sync;
+    sync.left = parts - 1;
+    {
+        std::lock_guard<std::mutex> l(p.mu);
+        for (int t = 1; t < parts; ++t)
+            p.jobs.emplace_back([&sync, &task, t] {
+                std::exception_ptr e;
+                try {
+                    task(t);
+                } catch (...) {
+                    e = std::current_exception();
+                }
+                std::lock_guard<std::mutex> g(sync.mu);
+                if (e && !sync.err) sync.err = e;
+                if (--sync.left == 0) sync.cv.notify_one();
+            });
+        p.pending.fetch_add(parts - 1, std::memory_order_release);
+    }
+    p.cv.notify_all();
+    std::exception_ptr mine;
+    try {
+        task(0);
+    } catch (...) {
+        mine = std::current_exception();
+    }
+    // help with queued work instead of sleeping: several callers may share the pool, and a pool with
+    // fewer workers than parts must still drain
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::lock_guard<std::mutex> l(p.mu);
+            if (p.jobs.empty()) break;
+            job = std::move(p.jobs.front());
+            p.jobs.pop_front();
+            p.pending.fetch_sub(1, std::memory_order_release);
+        }
+        job();
+    }
+    std::unique_lock<std::mutex> g(sync.mu);
+    sync.cv.wait(g, [&sync] { return sync.left == 0; });
+    if (mine) std::rethrow_exception(mine);
+    if (sync.err) std::rethrow_exception(sync.err);
+}
+
+// ------------------------------------------------------------------ pooled buffers
+
+namespace {
+
+constexpr size_t kPoolMaxBlocks = 48;
+constexpr size_t kDevPoolMaxBytes = (size_t)24 << 30; // of 288 GB HBM
+constexpr size_t kPinPoolMaxBytes = (size_t)4 << 30;
+
+size_t round_block(size_t n)
+{
+    const size_t g = n < ((size_t)1 << 20) ? (size_t)4096 : (size_t)1 << 20;
+    return (n + g - 1) / g * g;
+}
+
+// best fit among the free blocks: at least n bytes, at most twice that (+1 MiB)
+bool pool_take(std::vector<PoolBlock> &fl, size_t &cached, size_t n, PoolBlock *out)
+{
+    int best = -1;
+    for (int k = 0; k < (int)fl.size(); ++k)
+        if (fl[k].bytes >= n && fl[k].bytes <= 2 * n + ((size_t)1 << 20) && (best < 0 || fl[k].bytes < fl[best].bytes)) best = k;
+    if (best < 0) return false;
+    *out = fl[best];
+    cached -= fl[best].bytes;
+    fl.erase(fl.begin() + best);
+    return true;
+}
+
+} // namespace
+
+int DevBuf::alloc(agx_ctx *c, size_t n)
+{
+    release();
+    if (!c) {
+        agx_set_error("device allocation without a context");
+        return AGX_E_ARG;
+    }
+    if (n == 0) n = 16;
+    PoolBlock b{nullptr, 0};
+    bool hit;
+    {
+        std::lock_guard<std::mutex> l(c->pool_mu);
+        hit = pool_take(c->free_dev, c->cached_dev, n, &b);
+    }
+    if (!hit) {
+        b.bytes = round_block(n);
+        hipError_t e = hipMalloc(&b.p, b.bytes);
+        if (e != hipSuccess) { // give the cache back and try once more
+            std::vector<PoolBlock> drop;
+            {
+                std::lock_guard<std::mutex> l(c->pool_mu);
+                drop.swap(c->free_dev);
+                c->cached_dev = 0;
+            }
+            for (auto &d : drop) (void)hipFree(d.p);
+            e = hipMalloc(&b.p, b.bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            agx_set_error("hipMalloc(%zu) -> %s", b.bytes, hipGetErrorString(e));
+            return AGX_E_NOMEM;
+        }
+    }
+    ctx = c;
+    p = b.p;
+    block = b.bytes;
+    bytes = n;
+    return AGX_OK;
+}
+
+void DevBuf::release()
+{
+    if (p && ctx) {
+        void *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> l(ctx->pool_mu);
+            if (ctx->free_dev.size() < kPoolMaxBlocks && ctx->cached_dev + block <= kDevPoolMaxBytes) {
+                ctx->free_dev.push_back(PoolBlock{p, block});
+                ctx->cached_dev += block;
+            } else
+                drop = p;
+        }
+        if (drop) (void)hipFree(drop);
+    }
+    p = nullptr;
+    bytes = block = 0;
+    ctx = nullptr;
+}
+
+int PinBuf::alloc(agx_ctx *c, size_t n)
+{
+    release();
+    if (!c) {
+        agx_set_error("pinned allocation without a context");
+        return AGX_E_ARG;
+    }
+    if (n == 0) n = 16;
+    PoolBlock b{nullptr, 0};
+    bool hit;
+    {
+        std::lock_guard<std::mutex> l(c->pool_mu);
+        hit = pool_take(c->free_pin, c->cached_pin, n, &b);
+    }
+    if (!hit) {
+        b.bytes = round_block(n);
+        hipError_t e = hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            agx_set_error("hipHostMalloc(%zu) -> %s", b.bytes, hipGetErrorString(e));
+            return AGX_E_NOMEM;
+        }
+    }
+    ctx = c;
+    p = b.p;
+    block = b.bytes;
+    bytes = n;
+    return AGX_OK;
+}
+
+void PinBuf::release()
+{
+    if (p && ctx) {
+        void *drop = nullptr;
+        {
+            std::lock_guard<std::mutex> l(ctx->pool_mu);
+            if (ctx->free_pin.size() < kPoolMaxBlocks && ctx->cached_pin + block <= kPinPoolMaxBytes) {
+                ctx->free_pin.push_back(PoolBlock{p, block});
+                ctx->cached_pin += block;
+            } else
+                drop = p;
+        }
+        if (drop) (void)hipHostFree(drop);
+    }
+    p = nullptr;
+    bytes = block = 0;
+    ctx = nullptr;
+}
+
+// ------------------------------------------------------------------ launch fan-out
+
 int FanOut::begin()
 {
-    // AGX_FANOUT=0: every launch on the context's stream (experiments)
+    // AGX_FANOUT=0 (tuning build): every launch on the context's stream
     static const bool off = [] {
-        const char *e = getenv("AGX_FANOUT");
+        const char *e = agx_tune("AGX_FANOUT");
         return e && e[0] == '0';
     }();
     if (off) n = 1;
@@ -53,9 +329,65 @@ int FanOut::end()
     return AGX_OK;
 }
 
+// ------------------------------------------------------------------ contexts
+
+void agx_ctx_retain(agx_ctx *c)
+{
+    if (c) c->refs.fetch_add(1, std::memory_order_relaxed);
+}
+
+void agx_ctx_release(agx_ctx *c)
+{
+    if (!c) return;
+    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->free_dev) (void)hipFree(b.p);
+    for (auto &b : c->free_pin) (void)hipHostFree(b.p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    for (int k = 0; k < kAuxStreams; ++k) {
+        if (c->join[k]) (void)hipEventDestroy(c->join[k]);
+        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
+    }
+    if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int agx_shared_ctx(int device, int slot, agx_ctx **out)
+{
+    struct Entry {
+        int device, slot;
+        agx_ctx *ctx;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> table; // never freed: process lifetime
+    std::lock_guard<std::mutex> l(mu);
+    for (const Entry &e : table)
+        if (e.device == device && e.slot == slot) {
+            *out = e.ctx;
+            return AGX_OK;
+        }
+    agx_ctx *c = nullptr;
+    const int rc = agx_ctx_create(device, &c);
+    if (rc) return rc;
+    table.push_back(Entry{device, slot, c});
+    *out = c;
+    return AGX_OK;
+}
+
 extern "C" {
 
-const char *agx_version(void) { return "agx 0.1 (gfx950)"; }
+const char *agx_version(void)
+{
+#ifdef AGX_TUNING
+    return "agx 0.2 (gfx950, tuning build)";
+#else
+    return "agx 0.2 (gfx950)";
+#endif
+}
 const char *agx_last_error(void) { return g_err; }
 
 int agx_device_count(void)
@@ -92,6 +424,7 @@ int agx_ctx_create(int device, agx_ctx **out)
         return AGX_E_ARG;
     }
     *out = nullptr;
+    AGX_GUARD_BEGIN
     int n = agx_device_count();
     if (n <= 0) {
         agx_set_error("no HIP device is visible (this library has no CPU fallback)");
@@ -104,35 +437,24 @@ int agx_ctx_create(int device, agx_ctx **out)
     AGX_HIP(hipSetDevice(device));
     agx_ctx *c = new agx_ctx();
     c->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->n_cu = cus;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) c->own_stream = true;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {
         agx_set_error("context setup on device %d -> %s", device, hipGetErrorString(e));
-        agx_ctx_destroy(c);
+        agx_ctx_release(c);
         return AGX_E_HIP;
     }
-    c->own_stream = true;
     *out = c;
     return AGX_OK;
+    AGX_GUARD_END("agx_ctx_create")
 }
 
-void agx_ctx_destroy(agx_ctx *c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->fork) (void)hipEventDestroy(c->fork);
-    for (int k = 0; k < kAuxStreams; ++k) {
-        if (c->join[k]) (void)hipEventDestroy(c->join[k]);
-        if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
-    }
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
-}
+void agx_ctx_destroy(agx_ctx *c) { agx_ctx_release(c); }
 
 int agx_ctx_device(const agx_ctx *c) { return c ? c->device : -1; }
 void *agx_ctx_stream(const agx_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -148,6 +470,23 @@ int agx_ctx_set_stream(agx_ctx *c, void *s)
     c->stream = (hipStream_t)s;
     c->own_stream = false;
     return AGX_OK;
+}
+
+int agx_ctx_set_option(agx_ctx *c, int key, int64_t value)
+{
+    if (!c) {
+        agx_set_error("agx_ctx_set_option: null context");
+        return AGX_E_ARG;
+    }
+    switch (key) {
+    case AGX_OPT_SW_KERNEL:
+        if (value < AGX_SW_KERNEL_AUTO || value > AGX_SW_KERNEL_PACKED_BIASED) break;
+        c->opt_sw_kernel = (int)value;
+        return AGX_OK;
+    default: break;
+    }
+    agx_set_error("agx_ctx_set_option: unknown key %d or bad value %lld", key, (long long)value);
+    return AGX_E_ARG;
 }
 
 int agx_ctx_sync(agx_ctx *c)
@@ -176,6 +515,22 @@ int agx_ctx_timer_stop(agx_ctx *c, float *ms)
     AGX_HIP(hipEventElapsedTime(&t, c->ev0, c->ev1));
     if (ms) *ms = t;
     return AGX_OK;
+}
+
+void *agx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        agx_set_error("agx_host_alloc(%zu): no pinned memory (is a HIP device visible?)", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void agx_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 } // extern "C"

@@ -1,9 +1,20 @@
-// Host side of the Smith-Waterman path: validation, lane-tiling choice, packing into the
-// device image, launches, multi-device sharding (include/agx.h, "Smith-Waterman" section).
+// Host side of the Smith-Waterman path: validation, lane-tiling choice, wave formation, uploads,
+// launches, multi-device sharding (include/agx.h, "Smith-Waterman" section).
+//
+// What the host does per batch (agx_sw_batch_create), every step threaded over the process's pool:
+//   A  one pass over len[]: orientation (shorter sequence across the lanes), limits, cell count
+//   B  lane tiling per pair from a per-length lookup table (the lower envelope of the class cost lines),
+//      then the batch-level rules: tail regime, class consolidation, dominant shape
+//   C  two stable counting passes: long rows first, then (class, lanes per group)
+//   D  waves, group records and image offsets in closed form per (class, G) bucket
+// while the caller's `bases` and `off` arrays travel to the device as they are; a device kernel
+// (agx_sw_pack_kernel.hip) then builds the padded image and checks the symbols.  No byte of a sequence
+// is touched by the host.
 #include "agx_sw.h"
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <string>
 #include <thread>
 
@@ -17,105 +28,160 @@ struct Tiling {
     int G;
 };
 
-// AGX_SW_KERNEL=i32 selects the scalar int32 kernel, pk1 the first packed int16 formulation
-// (agx_sw_pk_kernel.hip); default is the biased packed one (agx_sw_pk2_kernel.hip, two pairs per lane
-// group) whenever its value range allows.  Scores are identical.
-int kernel_choice() // 0 = int32, 1 = packed (signed halves), 2 = packed (biased unsigned halves)
-{
-    static const int v = [] {
-        const char *e = getenv("AGX_SW_KERNEL");
-        if (e && strcmp(e, "i32") == 0) return 0;
-        if (e && strcmp(e, "pk1") == 0) return 1;
-        return 2;
-    }();
-    return v;
-}
-bool use_packed_kernel() { return kernel_choice() != 0; }
-
-// Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded
-// cells (the lanes of a wave that cannot host another group are charged to the pair), weighted
-// by the measured per-cell cost of the class.
-// beta: lanes' worth of extra weight on a wave's own duration (steps * C), which favours spreading long
-// pairs over more lanes.  0 in the throughput regime; the planner raises it for batches whose waves
-// would fill the chip a little more than once (see create_batch).  AGX_SW_TAIL_BETA overrides (experiments).
+// Tuning build only (see agx_tune): AGX_SW_TAIL_BETA, AGX_SW_MAX_C, AGX_SW_FORCE_C, AGX_SW_MAX_CLASSES,
+// AGX_SW_WAVES_PER_CLASS, AGX_SW_SORT_WAVES, AGX_SW_KERNEL.  The shipped library runs on the defaults.
 inline double tail_beta_override()
 {
     static const double v = [] {
-        const char *e = getenv("AGX_SW_TAIL_BETA");
+        const char *e = agx_tune("AGX_SW_TAIL_BETA");
         return e ? atof(e) : -1.0;
     }();
     return v;
 }
-
-inline double tiling_cost(bool packed, int ly, int ci, int G, double beta)
-{
-    const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
-    return (double)(ly + G - 1) * kSwClasses[ci] * ((64.0 / (double)(64 / G)) * wgt + beta);
-}
-
-// Tuning knob for experiments (not part of the ABI): AGX_SW_MAX_C caps the columns per lane.
 int max_cols_per_lane()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_SW_MAX_C");
+        const char *e = agx_tune("AGX_SW_MAX_C");
         const int n = e ? atoi(e) : 0;
         return n >= 4 ? n : AGX_SW_MAX_COLS_PER_LANE;
     }();
     return v;
 }
-
-// AGX_SW_FORCE_C pins the class (calibration runs only; pairs that do not fit 64 lanes fail).
 int force_cols_per_lane()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_SW_FORCE_C");
+        const char *e = agx_tune("AGX_SW_FORCE_C");
         return e ? atoi(e) : 0;
     }();
     return v;
 }
-
-// allowed: bit ci set = class ci may be used; *cost_out: the lane time estimate of the choice
-Tiling choose_tiling(bool packed, int lx, int ly, uint32_t allowed = ~0u, double *cost_out = nullptr, double beta = 0.0)
-{
-    Tiling best{-1, 0};
-    double best_cost = 0;
-    for (int ci = 0; ci < kSwNumClasses; ++ci) {
-        if (!((allowed >> ci) & 1u)) continue;
-        const int C = kSwClasses[ci];
-        const int G = (lx + C - 1) / C;
-        if (G > 64) continue;
-        if (C > max_cols_per_lane() && best.cls >= 0) continue;
-        if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
-        if ((packed ? kSwPkClassCost[ci] : kSwClassCost[ci]) == 0) continue; // class not built for this kernel
-        const double c = tiling_cost(packed, ly, ci, G, beta);
-        if (best.cls < 0 || c < best_cost || (c == best_cost && C > kSwClasses[best.cls])) {
-            best = Tiling{ci, G};
-            best_cost = c;
-        }
-    }
-    if (cost_out) *cost_out = best_cost;
-    return best;
-}
-
-// AGX_SW_MAX_CLASSES: upper bound on the kernel classes a mixed batch may spread over (default 6)
 int max_classes()
 {
     static const int v = [] {
-        const char *e = getenv("AGX_SW_MAX_CLASSES");
+        const char *e = agx_tune("AGX_SW_MAX_CLASSES");
         const int n = e ? atoi(e) : 0;
         return n > 0 ? n : 6;
     }();
     return v;
 }
+int tuned_kernel() // 0 = no override
+{
+    static const int v = [] {
+        const char *e = agx_tune("AGX_SW_KERNEL");
+        if (e && strcmp(e, "i32") == 0) return AGX_SW_KERNEL_INT32;
+        if (e && strcmp(e, "pk1") == 0) return AGX_SW_KERNEL_PACKED_SIGNED;
+        if (e && strcmp(e, "pk2") == 0) return AGX_SW_KERNEL_PACKED_BIASED;
+        return 0;
+    }();
+    return v;
+}
+
+// per-class cost table of the kernel family a batch runs (relative lane time per padded cell)
+inline const double *class_costs(int family) // 0 int32, 1 packed signed, 2 packed biased
+{
+    return family == 0 ? kSwClassCost : family == 1 ? kSwPkClassCost : kSwPk2ClassCost;
+}
+
+// Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded cells (the
+// lanes of a wave that cannot host another group are charged to the pair), weighted by the measured
+// per-cell cost of the class.  beta: lanes' worth of extra weight on a wave's own duration (steps * C),
+// which favours spreading long pairs over more lanes; 0 in the throughput regime.
+inline double tiling_slope(const double *costs, int ci, int G, double beta)
+{
+    return kSwClasses[ci] * ((64.0 / (double)(64 / G)) * costs[ci] + beta);
+}
+
+// The choice for one shorter length lx as a function of the longer length ly: cost_i(ly) = (ly + G_i - 1) * w_i
+// is a line per class, the best class is their lower envelope -- a handful of segments.
+struct TilingSeg {
+    uint32_t ly_from; // the segment covers [ly_from, next segment's ly_from)
+    uint8_t cls, G;
+    double w;
+};
+struct TilingTable {
+    std::vector<uint32_t> first; // index of lx's first segment; first[lx + 1] ends it (no segment = no class spans lx)
+    std::vector<TilingSeg> segs;
+    inline bool pick(uint32_t lx, uint32_t ly, Tiling *t, double *cost) const
+    {
+        const uint32_t a = first[lx], b = first[lx + 1];
+        if (a == b) return false;
+        uint32_t k = a;
+        while (k + 1 < b && segs[k + 1].ly_from <= ly) ++k;
+        const TilingSeg &s = segs[k];
+        *t = Tiling{s.cls, s.G};
+        if (cost) *cost = (double)(ly + s.G - 1) * s.w;
+        return true;
+    }
+};
+
+// present[lx] != 0: some pair of the batch has that shorter length (only those rows are built)
+void build_tiling_table(TilingTable &tt, const std::vector<uint8_t> &present, const double *costs, uint32_t allowed, double beta)
+{
+    const uint32_t n_lx = (uint32_t)present.size();
+    std::vector<std::vector<TilingSeg>> rows(n_lx);
+    agx_parallel_for((int64_t)n_lx, 64, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t lx = std::max<int64_t>(lo, 1); lx < hi; ++lx) {
+            if (!present[(size_t)lx]) continue;
+            struct Line {
+                int ci, G;
+                double w;
+            } ln[kSwNumClasses];
+            int n = 0;
+            for (int ci = 0; ci < kSwNumClasses; ++ci) {
+                if (!((allowed >> ci) & 1u)) continue;
+                const int C = kSwClasses[ci];
+                const int G = ((int)lx + C - 1) / C;
+                if (G > 64) continue;
+                if (C > max_cols_per_lane() && n > 0) continue;
+                if (force_cols_per_lane() && C != force_cols_per_lane()) continue;
+                if (costs[ci] == 0) continue; // class not built for this kernel
+                ln[n++] = Line{ci, G, tiling_slope(costs, ci, G, beta)};
+            }
+            if (n == 0) continue;
+            auto cost_at = [&](int k, double ly) { return (ly + ln[k].G - 1) * ln[k].w; };
+            // start at ly = lx (the longer side is never shorter); ties go to the wider class
+            int cur = 0;
+            for (int k = 1; k < n; ++k)
+                if (cost_at(k, (double)lx) <= cost_at(cur, (double)lx)) cur = k;
+            uint32_t from = (uint32_t)lx;
+            std::vector<TilingSeg> &row = rows[(size_t)lx];
+            for (;;) {
+                row.push_back(TilingSeg{from, (uint8_t)ln[cur].ci, (uint8_t)ln[cur].G, ln[cur].w});
+                // the next line to undercut the current one: smaller slope, first ly where it is strictly cheaper
+                int nxt = -1;
+                double nxt_at = 0;
+                for (int k = 0; k < n; ++k) {
+                    if (!(ln[k].w < ln[cur].w)) continue;
+                    const double x = ((ln[k].G - 1) * ln[k].w - (ln[cur].G - 1) * ln[cur].w) / (ln[cur].w - ln[k].w);
+                    double at = std::floor(x) + 1;
+                    if (at <= (double)from) at = (double)from + 1;
+                    if (nxt < 0 || at < nxt_at || (at == nxt_at && ln[k].w < ln[nxt].w)) {
+                        nxt = k;
+                        nxt_at = at;
+                    }
+                }
+                if (nxt < 0 || nxt_at > 65535.0) break;
+                cur = nxt;
+                from = (uint32_t)nxt_at;
+            }
+        }
+    });
+    tt.first.assign((size_t)n_lx + 1, 0);
+    tt.segs.clear();
+    for (uint32_t lx = 0; lx < n_lx; ++lx) {
+        tt.first[lx] = (uint32_t)tt.segs.size();
+        tt.segs.insert(tt.segs.end(), rows[lx].begin(), rows[lx].end());
+    }
+    tt.first[n_lx] = (uint32_t)tt.segs.size();
+}
 
 // Uniform batches (most pairs share one shape, e.g. fixed-length reads): every wave of that shape
 // costs the same, so the launch lasts ceil(waves / SIMDs) wave-times -- the tiling is chosen for the
 // whole shape with that quantisation instead of pair by pair.
-Tiling choose_tiling_uniform(bool packed, int lx, int ly, int64_t count, int n_simd)
+Tiling choose_tiling_uniform(const double *costs, int slots, int lx, int ly, int64_t count, int n_simd)
 {
     Tiling best{-1, 0};
     double best_cost = 0;
-    const int slots = packed ? 2 : 1;
     for (int ci = 0; ci < kSwNumClasses; ++ci) {
         const int C = kSwClasses[ci];
         const int G = (lx + C - 1) / C;
@@ -125,7 +191,7 @@ Tiling choose_tiling_uniform(bool packed, int lx, int ly, int64_t count, int n_s
         const int64_t per_wave = (int64_t)(64 / G) * slots;
         const int64_t waves = (count + per_wave - 1) / per_wave;
         const int64_t rounds = (waves + n_simd - 1) / n_simd;
-        const double wgt = packed ? kSwPkClassCost[ci] : kSwClassCost[ci];
+        const double wgt = costs[ci];
         if (wgt == 0) continue;
         const double c = (double)rounds * (ly + G - 1) * C * wgt;
         if (best.cls < 0 || c < best_cost) {
@@ -136,13 +202,15 @@ Tiling choose_tiling_uniform(bool packed, int lx, int ly, int64_t count, int n_s
     return best;
 }
 
-struct PairPlan {
+constexpr uint8_t kClsEmpty = 255;   // an empty side: nothing to fill
+constexpr uint8_t kClsUntiled = 254; // pass A done, no tiling yet
+struct PairPlan {                    // 12 bytes: the sorts move these
     uint32_t pair;
-    uint16_t lx;
     uint32_t ly;
+    uint16_t lxo; // lx | (1 = sequence 2p+1 is the shorter one) << 15, as the group records carry it
     uint8_t cls;
     uint8_t G;
-    uint8_t x_is_second; // 1 = sequence 2p+1 is the shorter one
+    uint32_t lx() const { return lxo & 0x7fffu; }
 };
 
 struct ClassLaunch {
@@ -150,12 +218,55 @@ struct ClassLaunch {
     uint32_t first_wave = 0, n_waves = 0;
 };
 
+// one (class, G) run of the sorted plan: entry j of the run is slot j % slots of its group j / slots,
+// a wave takes 64 / G groups
+struct Bucket {
+    size_t first = 0, count = 0;     // entries of plan[]
+    size_t group0 = 0, n_groups = 0; // group records
+    size_t wave0 = 0, n_waves = 0;
+    int cls = 0, G = 0;
+};
+
+// Stable counting sort of src into dst by key(e) in [0, n_keys), threaded: every part counts its
+// contiguous chunk, the offsets are laid out key-major / part-minor, every part scatters its chunk in order.
+template <typename T, typename KeyFn>
+void counting_sort(const std::vector<T> &src, std::vector<T> &dst, size_t n_keys, KeyFn key)
+{
+    const size_t n = src.size();
+    dst.resize(n);
+    const int parts = (int)std::min<int64_t>(agx_host_threads(), std::max<int64_t>(1, (int64_t)n / 32768));
+    std::vector<std::vector<uint32_t>> cnt((size_t)parts);
+    const size_t chunk = (n + parts - 1) / (size_t)parts;
+    agx_pool_run(parts, [&](int t) {
+        std::vector<uint32_t> &c = cnt[(size_t)t];
+        c.assign(n_keys, 0);
+        const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
+        for (size_t i = b; i < e; ++i) ++c[key(src[i])];
+    });
+    uint32_t run = 0;
+    for (size_t k = 0; k < n_keys; ++k)
+        for (int t = 0; t < parts; ++t) {
+            const uint32_t c = cnt[(size_t)t][k];
+            cnt[(size_t)t][k] = run;
+            run += c;
+        }
+    agx_pool_run(parts, [&](int t) {
+        std::vector<uint32_t> &c = cnt[(size_t)t];
+        const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
+        for (size_t i = b; i < e; ++i) dst[c[key(src[i])]++] = src[i];
+    });
+}
+
+inline double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 } // namespace
 
 struct agx_sw_batch {
-    agx_ctx *ctx = nullptr;
-    bool packed = false;
-    bool biased = false; // packed batches: the biased formulation (agx_sw_pk2_kernel.hip)
+    agx_ctx *ctx = nullptr; // retained
+    int family = 0;         // 0 int32, 1 packed signed, 2 packed biased
     SwParams prm{};
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
@@ -181,6 +292,7 @@ void agx_sw_batch_destroy(agx_sw_batch *b)
     b->waves.release();
     b->scores.release();
     b->table.release();
+    agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
     delete b;
 }
 
@@ -193,7 +305,9 @@ int agx_sw_batch_create(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off,
 int agx_sw_batch_create_scored(agx_ctx *ctx, const agx_sw_scoring *scoring, const uint8_t *bases, const uint64_t *off,
                                const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
 {
+    AGX_GUARD_BEGIN
     return create_batch(ctx, scoring, nullptr, bases, off, len, n_pairs, out);
+    AGX_GUARD_END("agx_sw_batch_create")
 }
 
 int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const uint8_t *bases, const uint64_t *off,
@@ -203,7 +317,9 @@ int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const 
         agx_set_error("agx_sw_batch_create_matrix: matrix is NULL");
         return AGX_E_ARG;
     }
+    AGX_GUARD_BEGIN
     return create_batch(ctx, nullptr, matrix, bases, off, len, n_pairs, out);
+    AGX_GUARD_END("agx_sw_batch_create_matrix")
 }
 
 } // extern "C"
@@ -282,32 +398,13 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     prm.gf2 = twice(prm.gf);
     prm.hd2 = twice(prm.hd);
     prm.delta2 = twice(prm.delta);
-    // the packed int16 kernel covers shorter sides up to 64 x 40 columns; one longer pair moves the
-    // whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160)
-    bool packed = use_packed_kernel() && !matrix; // the matrix lookup exists in the int32 kernel only
-    uint32_t longest_short = 0;
-    if (packed)
-        for (int64_t p = 0; p < n_pairs; ++p) {
-            const uint32_t sh = std::min(len[2 * p], len[2 * p + 1]);
-            longest_short = std::max(longest_short, sh);
-            if (sh > (uint32_t)kSwPackedMaxShort) {
-                packed = false;
-                break;
-            }
-        }
-    // Biased formulation: every stored half must be the pattern of a positive normal half-precision number,
-    // [0x0400, 0x7c00).  Smallest: B - max(|gf| + |ge|, delta); largest: B + (longest shorter side + 1) * match + |gf|.
     prm.age2 = twice(-prm.ge);
     prm.agf2 = twice(-prm.gf);
     const int bias = 0x0400 + std::max(-prm.gf - prm.ge, prm.delta);
     prm.bias2 = twice(bias);
-    const bool biased = packed && kernel_choice() == 2 &&
-                        (int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00;
-    const uint32_t max_short = matrix ? (uint32_t)kSwPackedMaxShort : AGX_SW_MAX_SHORT_LEN; // no wide classes in matrix mode
 
-    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_begin = now();
+    const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
+    const double t_begin = now_ms();
     if (n_pairs > 0 && !bases) {
         for (int64_t p = 0; p < 2 * n_pairs; ++p)
             if (len[p]) {
@@ -316,151 +413,338 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             }
     }
 
-    // ---- plan every pair (threads over pairs): validate, orient, choose the lane tiling
-    const double beta0 = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
+    // ---- pass A (threads over pairs): orient, check the limits, count cells, extent of `bases`
     std::vector<PairPlan> all((size_t)n_pairs);
+    const uint32_t hard_max_short = matrix ? (uint32_t)kSwPackedMaxShort : AGX_SW_MAX_SHORT_LEN; // no wide classes in matrix mode
     struct Worker {
         int rc = AGX_OK;
         int64_t bad_pair = -1;
-        int64_t cells = 0;
+        int64_t cells = 0, votes = 0;
+        uint32_t longest_short = 0, longest_long = 0;
+        uint32_t shape0 = 0xffffffffu; // first (lx, ly) this part saw
+        bool mixed = false;            // ... and whether it saw another one
+        int64_t n_fill = 0;
+        uint64_t lo = ~0ull, hi = 0, sum_len = 0;
         double waves = 0;
-        double class_work[sizeof(kSwClasses) / sizeof(kSwClasses[0])] = {};
+        double class_work[kSwNumClasses] = {};
+        std::vector<uint8_t> present; // [lx] != 0: this part saw that shorter length
     };
     std::vector<Worker> wk((size_t)agx_host_threads());
-    agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
+    agx_parallel_for(n_pairs, 8192, [&](int64_t lo, int64_t hi, int tid) {
         Worker &me = wk[(size_t)tid];
+        me.present.assign((size_t)hard_max_short + 1, 0);
         for (int64_t p = lo; p < hi; ++p) {
             PairPlan &pp = all[(size_t)p];
             pp = PairPlan{};
             pp.pair = (uint32_t)p;
-            pp.cls = 255; // 255 = nothing to fill
+            pp.cls = kClsEmpty;
             const uint32_t la = len[2 * p], lb = len[2 * p + 1];
             me.cells += (int64_t)la * lb;
+            me.sum_len += (uint64_t)la + lb;
+            if (la) {
+                me.lo = std::min(me.lo, off[2 * p]);
+                me.hi = std::max(me.hi, off[2 * p] + la);
+            }
+            if (lb) {
+                me.lo = std::min(me.lo, off[2 * p + 1]);
+                me.hi = std::max(me.hi, off[2 * p + 1] + lb);
+            }
             if (la == 0 || lb == 0) continue; // no interior cell: score stays 0
             const bool second_short = lb < la; // ties keep file order (antidiagonalSmithWaterman.c:229-244)
             const uint32_t lx = second_short ? lb : la, ly = second_short ? la : lb;
-            int rc = AGX_OK;
-            Tiling tl{-1, 0};
-            bool bad_symbol;
-            if (matrix) { // any byte outside the alphabet maps to 0xff
-                const uint8_t *q = bases + off[2 * p], *r = bases + off[2 * p + 1];
-                uint8_t bad = 0;
-                for (uint32_t k = 0; k < la; ++k) bad |= (uint8_t)(matrix->code[q[k]] == 0xff);
-                for (uint32_t k = 0; k < lb; ++k) bad |= (uint8_t)(matrix->code[r[k]] == 0xff);
-                bad_symbol = bad != 0;
-            } else
-                bad_symbol = memchr(bases + off[2 * p], 0, la) || memchr(bases + off[2 * p + 1], 0, lb);
-            if (lx > max_short || ly > 0xffffu) rc = AGX_E_LIMIT;
-            else if (bad_symbol) rc = AGX_E_SYMBOL;
-            else {
-                double cost = 0;
-                tl = choose_tiling(packed, (int)lx, (int)ly, ~0u, &cost, beta0);
-                if (tl.cls < 0 || (matrix && kSwClasses[tl.cls] > 40)) rc = AGX_E_LIMIT; // no wide classes in matrix mode
-                else {
-                    me.class_work[tl.cls] += cost;
-                    me.waves += (double)tl.G / 64.0 / (packed ? 2 : 1);
-                }
-            }
-            if (rc != AGX_OK) {
+            if (lx > hard_max_short || ly > 0xffffu) {
                 if (me.rc == AGX_OK) {
-                    me.rc = rc;
+                    me.rc = AGX_E_LIMIT;
                     me.bad_pair = p;
                 }
                 continue;
             }
-            pp.lx = (uint16_t)lx;
+            me.longest_short = std::max(me.longest_short, lx);
+            me.longest_long = std::max(me.longest_long, ly);
+            me.present[lx] = 1;
+            const uint32_t key = lx << 16 | ly;
+            if (me.shape0 == 0xffffffffu) me.shape0 = key;
+            else if (key != me.shape0) me.mixed = true;
+            ++me.n_fill;
+            pp.lxo = (uint16_t)(lx | (second_short ? 0x8000u : 0u));
             pp.ly = ly;
-            pp.cls = (uint8_t)tl.cls;
-            pp.G = (uint8_t)tl.G;
-            pp.x_is_second = second_short ? 1 : 0;
+            pp.cls = kClsUntiled;
         }
     });
     int64_t cells = 0;
-    for (const Worker &w : wk) cells += w.cells;
+    uint32_t longest_short = 0, longest_long = 0;
+    uint64_t ext_lo = ~0ull, ext_hi = 0, sum_len = 0;
+    for (const Worker &w : wk) {
+        cells += w.cells;
+        longest_short = std::max(longest_short, w.longest_short);
+        longest_long = std::max(longest_long, w.longest_long);
+        ext_lo = std::min(ext_lo, w.lo);
+        ext_hi = std::max(ext_hi, w.hi);
+        sum_len += w.sum_len;
+    }
     for (const Worker &w : wk)
         if (w.rc != AGX_OK) {
             const int64_t p = w.bad_pair;
-            if (w.rc == AGX_E_SYMBOL && matrix)
-                agx_set_error("pair %lld contains a byte outside the substitution matrix's alphabet", (long long)p);
-            else if (w.rc == AGX_E_SYMBOL)
-                agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)p);
+            agx_set_error("pair %lld: lengths %u x %u exceed the supported %u x 65535 (shorter x longer)", (long long)p,
+                          len[2 * p], len[2 * p + 1], hard_max_short);
+            return w.rc;
+        }
+    if (ext_hi < ext_lo) ext_lo = ext_hi = 0; // no byte at all
+    std::vector<uint8_t> present((size_t)longest_short + 1, 0);
+    for (const Worker &w : wk)
+        for (size_t lx = 0; lx < present.size() && lx < w.present.size(); ++lx) present[lx] |= w.present[lx];
+    const double t_pass_a = now_ms();
+
+    // ---- kernel family.  The packed int16 kernels cover shorter sides up to 64 x 40 columns; one longer
+    // pair moves the whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160).
+    // Biased formulation: every stored half must be the pattern of a positive normal half-precision number,
+    // [0x0400, 0x7c00): smallest B - max(|gf| + |ge|, delta), largest B + (longest shorter side + 1) * match + |gf|.
+    const int want = tuned_kernel() ? tuned_kernel() : ctx ? ctx->opt_sw_kernel : AGX_SW_KERNEL_AUTO;
+    int family = want == AGX_SW_KERNEL_INT32 ? 0 : want == AGX_SW_KERNEL_PACKED_SIGNED ? 1 : 2;
+    if (matrix || longest_short > (uint32_t)kSwPackedMaxShort) family = 0; // the matrix lookup exists in the int32 kernel only
+    if (family == 2 && !((int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00)) family = 1;
+    const bool packed = family != 0;
+    const double *costs = class_costs(family);
+    const int slots = packed ? 2 : 1;
+
+    // plan-only batches check the symbols on the host; with a device the pack kernel does it
+    if (!ctx && n_pairs > 0) {
+        std::vector<int64_t> bad((size_t)agx_host_threads(), -1);
+        agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
+            for (int64_t p = lo; p < hi && bad[(size_t)tid] < 0; ++p) {
+                const uint32_t la = len[2 * p], lb = len[2 * p + 1];
+                if (la == 0 || lb == 0) continue;
+                const uint8_t *q = bases + off[2 * p], *r = bases + off[2 * p + 1];
+                bool hit = false;
+                if (matrix) {
+                    for (uint32_t k = 0; k < la; ++k) hit |= matrix->code[q[k]] == 0xff;
+                    for (uint32_t k = 0; k < lb; ++k) hit |= matrix->code[r[k]] == 0xff;
+                } else
+                    hit = memchr(q, 0, la) || memchr(r, 0, lb);
+                if (hit) bad[(size_t)tid] = p;
+            }
+        });
+        int64_t first_bad = -1;
+        for (int64_t v : bad)
+            if (v >= 0 && (first_bad < 0 || v < first_bad)) first_bad = v;
+        if (first_bad >= 0) {
+            if (matrix)
+                agx_set_error("pair %lld contains a byte outside the substitution matrix's alphabet", (long long)first_bad);
             else
-                agx_set_error("pair %lld: lengths %u x %u exceed the supported %u x 65535 (shorter x longer)", (long long)p,
-                              len[2 * p], len[2 * p + 1], max_short);
+                agx_set_error("pair %lld contains byte 0x00, which is reserved as the padding symbol", (long long)first_bad);
+            return AGX_E_SYMBOL;
+        }
+    }
+
+    agx_sw_batch *b = new agx_sw_batch();
+    struct Guard { // error paths: free whatever the batch holds
+        agx_sw_batch *&b;
+        ~Guard()
+        {
+            if (b) agx_sw_batch_destroy(b);
+        }
+    } guard{b};
+    agx_ctx_retain(ctx);
+    b->ctx = ctx;
+    b->n_pairs = n_pairs;
+    b->family = family;
+    b->matrix = matrix != nullptr;
+    b->prm = prm;
+
+    // ---- the caller's arrays start travelling now, while the plan is made: a helper thread drives the
+    // copies (a pageable source makes hipMemcpyAsync block while the runtime stages it)
+    DevBuf d_raw, d_off, d_code, d_flag;
+    PinBuf h_groups, h_waves, h_flag, h_dense, h_dense_off;
+    struct Temps {
+        DevBuf *d[4];
+        PinBuf *h[5];
+        ~Temps()
+        {
+            for (DevBuf *x : d) x->release();
+            for (PinBuf *x : h) x->release();
+        }
+    } temps{{&d_raw, &d_off, &d_code, &d_flag}, {&h_groups, &h_waves, &h_flag, &h_dense, &h_dense_off}};
+    // `bases` is normally dense; a caller whose sequences are islands in a much larger array gets a dense
+    // copy (pinned, its own offsets) instead of an upload of the gaps
+    const bool dense_copy = (ext_hi - ext_lo) > 4 * sum_len + ((uint64_t)64 << 20);
+    const uint64_t raw_bytes = dense_copy ? sum_len : ext_hi - ext_lo;
+    const uint64_t raw_base = dense_copy ? 0 : ext_lo;
+    int up_rc = AGX_OK;
+    char up_err[300] = "";
+    auto upload_inputs = [&]() {
+        try {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                up_rc = AGX_E_HIP;
+                snprintf(up_err, sizeof up_err, "hipSetDevice failed on the upload thread");
+                return;
+            }
+            int r = d_raw.alloc(ctx, (size_t)raw_bytes + 64);
+            if (!r) r = d_off.alloc(ctx, (size_t)n_pairs * 2 * sizeof(uint64_t));
+            if (!r) r = d_flag.alloc(ctx, 2 * sizeof(uint32_t));
+            if (!r && matrix) r = d_code.alloc(ctx, 256);
+            const uint8_t *src = bases + ext_lo;
+            const uint64_t *src_off = off;
+            if (!r && dense_copy) {
+                r = h_dense.alloc(ctx, (size_t)sum_len + 16);
+                if (!r) r = h_dense_off.alloc(ctx, (size_t)n_pairs * 2 * sizeof(uint64_t));
+                if (!r) {
+                    uint64_t *o = (uint64_t *)h_dense_off.p, at = 0;
+                    for (int64_t k = 0; k < 2 * n_pairs; ++k) {
+                        o[k] = at;
+                        if (len[k]) memcpy((uint8_t *)h_dense.p + at, bases + off[k], len[k]);
+                        at += len[k];
+                    }
+                    src = (const uint8_t *)h_dense.p;
+                    src_off = o;
+                }
+            }
+            if (r) {
+                up_rc = r;
+                snprintf(up_err, sizeof up_err, "%s", agx_last_error());
+                return;
+            }
+            hipError_t e = hipSuccess;
+            if (raw_bytes) e = hipMemcpyAsync(d_raw.p, src, (size_t)raw_bytes, hipMemcpyHostToDevice, ctx->copy);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_off.p, src_off, (size_t)n_pairs * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy);
+            if (e == hipSuccess && matrix) e = hipMemcpyAsync(d_code.p, matrix->code, 256, hipMemcpyHostToDevice, ctx->copy);
+            if (e == hipSuccess) e = hipMemsetAsync(d_flag.p, 0, 4, ctx->copy);                    // [0] offending pairs
+            if (e == hipSuccess) e = hipMemsetAsync((char *)d_flag.p + 4, 0xff, 4, ctx->copy);     // [1] smallest of them
+            if (e != hipSuccess) {
+                up_rc = AGX_E_HIP;
+                snprintf(up_err, sizeof up_err, "upload of the sequences -> %s", hipGetErrorString(e));
+            }
+        } catch (const std::exception &ex) {
+            up_rc = AGX_E_NOMEM;
+            snprintf(up_err, sizeof up_err, "upload thread: %s", ex.what());
+        }
+    };
+    std::thread uploader;
+    struct Joiner {
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{uploader};
+    if (ctx && n_pairs > 0) uploader = std::thread(upload_inputs);
+
+    // ---- uniform batches (fixed-length reads: BASELINE config 2): one shape, so one tiling -- chosen with the
+    // wave-count quantisation below -- and nothing to sort: file order is already the order passes B and C
+    // would produce.
+    std::vector<PairPlan> plan;
+    bool planned = false;
+    {
+        int64_t n_fill = 0;
+        uint32_t shape = 0xffffffffu;
+        bool one_shape = true;
+        for (const Worker &w : wk) {
+            n_fill += w.n_fill;
+            if (w.mixed) one_shape = false;
+            if (w.shape0 != 0xffffffffu) {
+                if (shape == 0xffffffffu) shape = w.shape0;
+                else if (shape != w.shape0) one_shape = false;
+            }
+        }
+        if (one_shape && n_fill == n_pairs && n_pairs >= 1024 && n_cu > 0) {
+            const Tiling tl = choose_tiling_uniform(costs, slots, (int)(shape >> 16), (int)(shape & 0xffffu), n_pairs, 4 * n_cu);
+            if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
+                agx_parallel_for(n_pairs, 32768, [&](int64_t lo, int64_t hi, int) {
+                    for (int64_t p = lo; p < hi; ++p) {
+                        all[(size_t)p].cls = (uint8_t)tl.cls;
+                        all[(size_t)p].G = (uint8_t)tl.G;
+                    }
+                });
+                plan.swap(all);
+                planned = true;
+            }
+        }
+    }
+    double t_plan = now_ms(), t_sort = t_plan;
+
+    // ---- pass B: lane tiling per pair, then the batch-level rules.  Host-only work from here to the records.
+    if (!planned) {
+    TilingTable tt;
+    double beta_used = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
+    auto tile_all = [&](uint32_t allowed, double beta, bool only_outside) {
+        build_tiling_table(tt, present, costs, allowed, beta);
+        for (Worker &w : wk) {
+            w.waves = 0;
+            w.rc = AGX_OK;
+            for (double &c : w.class_work) c = 0;
+        }
+        agx_parallel_for(n_pairs, 8192, [&](int64_t lo, int64_t hi, int tid) {
+            Worker &me = wk[(size_t)tid];
+            for (int64_t p = lo; p < hi; ++p) {
+                PairPlan &pp = all[(size_t)p];
+                if (pp.cls == kClsEmpty) continue;
+                Tiling tl;
+                double cost = 0;
+                const bool keep_own = only_outside && pp.cls < kSwNumClasses && ((allowed >> pp.cls) & 1u);
+                if (!keep_own && tt.pick(pp.lx(), pp.ly, &tl, &cost) && !(matrix && kSwClasses[tl.cls] > 40)) {
+                    pp.cls = (uint8_t)tl.cls;
+                    pp.G = (uint8_t)tl.G;
+                } else if (pp.cls == kClsUntiled) { // no class spans this pair (cannot happen within the limits)
+                    if (me.rc == AGX_OK) {
+                        me.rc = AGX_E_LIMIT;
+                        me.bad_pair = p;
+                    }
+                    continue;
+                } else // keeps the class it has
+                    cost = (double)(pp.ly + pp.G - 1) * tiling_slope(costs, pp.cls, pp.G, beta);
+                me.class_work[pp.cls] += cost;
+                me.waves += (double)pp.G / 64.0 / slots;
+            }
+        });
+    };
+    tile_all(~0u, beta_used, false);
+    for (const Worker &w : wk)
+        if (w.rc != AGX_OK) {
+            agx_set_error("pair %lld: no lane tiling fits its %u columns", (long long)w.bad_pair, all[(size_t)w.bad_pair].lx());
             return w.rc;
         }
     // Tail regime: when the planned waves fill the chip's resident capacity (about 5 per SIMD for this
     // kernel) less than 1.6 times, a launch lasts as long as its longest waves -- alone on their SIMDs
     // in a small batch, or stranded in a mostly empty second filling.  Such a batch is re-tiled with a
-    // term on a wave's own duration (3 lanes' worth): long pairs spread over more lanes, waves get
-    // shorter and more numerous.  Mixed 32..512 batches (tools/sw_tail_beta_sweep.py,
-    // sw_tail_rule_check.py): 8192 pairs 1.24 -> 2.6 TCUPS, 16 384 2.46 -> 2.9, 131 072 4.15 -> 4.61;
-    // beyond 1.6 fillings the term costs 1-3 % and is left out.  (Uniform batches are re-tiled below
-    // with their own wave-count model.)
-    double beta_used = beta0;
+    // term on a wave's own duration (3 lanes' worth; more the emptier the chip): long pairs spread over
+    // more lanes, waves get shorter and more numerous (tools/sw_tail_beta_sweep.py, sw_tail_rule_check.py:
+    // mixed 32..512 pairs, 8192 pairs 1.24 -> 2.6 TCUPS, 16 384 2.46 -> 2.9, 131 072 4.15 -> 4.61).  Beyond
+    // 1.6 fillings the term costs 1-3 % and is left out.  (Uniform batches are re-tiled below with their
+    // own wave-count model.)
     if (tail_beta_override() < 0 && n_cu > 0) {
         double waves_est = 0;
         for (const Worker &w : wk) waves_est += w.waves;
         const double fill = waves_est / (5.0 * 4.0 * n_cu);
         if (fill < 1.6) {
-            // the emptier the chip, the more a wave's own duration counts (sweep of 2048 ... 131 072 pairs)
             beta_used = fill < 0.1 ? 10.0 : fill < 0.4 ? 6.0 : 3.0;
-            for (Worker &w : wk) {
-                w.waves = 0;
-                for (double &c : w.class_work) c = 0;
-            }
-            agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int tid) {
-                Worker &me = wk[(size_t)tid];
-                for (int64_t p = lo; p < hi; ++p) {
-                    PairPlan &pp = all[(size_t)p];
-                    if (pp.cls == 255) continue;
-                    double cost = 0;
-                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, ~0u, &cost, beta_used);
-                    if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
-                        pp.cls = (uint8_t)tl.cls;
-                        pp.G = (uint8_t)tl.G;
-                    }
-                    me.class_work[pp.cls] += cost;
-                    me.waves += (double)pp.G / 64.0 / (packed ? 2 : 1);
-                }
-            });
+            tile_all(~0u, beta_used, false);
         }
     }
     // Every class is its own launch and the measured cost curve is flat over many widths: a mixed batch
     // keeps the classes that carry most of the work -- about one per 4096 wavefronts, at most 6
-    // (tools/sw_mixed_sweep.py: 16384 pairs of 32..512 went from 0.63 to 2.5 TCUPS, 65536 from 2.1 to 3.9) -- and
-    // re-tiles the other pairs among them (a pair no kept class can span keeps its own).
+    // (tools/sw_mixed_sweep.py: 16384 pairs of 32..512 went from 0.63 to 2.5 TCUPS, 65536 from 2.1 to 3.9) --
+    // and re-tiles the other pairs among them (a pair no kept class can span keeps its own).
     {
-        double work[sizeof(kSwClasses) / sizeof(kSwClasses[0])] = {};
+        double work[kSwNumClasses] = {};
         double waves_est = 0;
         for (const Worker &w : wk) {
             waves_est += w.waves;
             for (int c = 0; c < kSwNumClasses; ++c) work[c] += w.class_work[c];
         }
         static const double per_class = [] {
-            const char *e = getenv("AGX_SW_WAVES_PER_CLASS");
+            const char *e = agx_tune("AGX_SW_WAVES_PER_CLASS");
             return e && atof(e) > 0 ? atof(e) : 4096.0;
         }();
         const int k_max = std::min(max_classes(), 1 + (int)(waves_est / per_class));
         int used = 0;
         for (int c = 0; c < kSwNumClasses; ++c) used += work[c] > 0;
         if (used > k_max) {
-            int order[sizeof(kSwClasses) / sizeof(kSwClasses[0])];
+            int order[kSwNumClasses];
             for (int c = 0; c < kSwNumClasses; ++c) order[c] = c;
             std::sort(order, order + kSwNumClasses, [&](int x, int y) { return work[x] > work[y]; });
             uint32_t keep = 0;
             for (int k = 0; k < k_max; ++k) keep |= 1u << order[k];
-            agx_parallel_for(n_pairs, 4096, [&](int64_t lo, int64_t hi, int) {
-                for (int64_t p = lo; p < hi; ++p) {
-                    PairPlan &pp = all[(size_t)p];
-                    if (pp.cls == 255 || ((keep >> pp.cls) & 1u)) continue;
-                    const Tiling tl = choose_tiling(packed, (int)pp.lx, (int)pp.ly, keep, nullptr, beta_used);
-                    if (tl.cls >= 0) {
-                        pp.cls = (uint8_t)tl.cls;
-                        pp.G = (uint8_t)tl.G;
-                    }
-                }
-            });
+            tile_all(keep, beta_used, true);
         }
     }
     // dominant shape?  (sampled first, counted only if the sample says so)
@@ -468,232 +752,265 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         const size_t stride = (size_t)n_pairs / 512;
         uint32_t cand = 0;
         int votes = 0;
+        auto shape = [](const PairPlan &pp) { return pp.lx() << 16 | (pp.ly & 0xffffu); };
         for (size_t k = 0; k < 512; ++k) { // Boyer-Moore majority vote over a sample
             const PairPlan &pp = all[k * stride];
-            const uint32_t key = (uint32_t)pp.lx << 16 | (pp.ly & 0xffffu);
-            if (pp.cls == 255) continue;
+            if (pp.cls == kClsEmpty) continue;
             if (votes == 0) {
-                cand = key;
+                cand = shape(pp);
                 votes = 1;
             } else
-                votes += key == cand ? 1 : -1;
+                votes += shape(pp) == cand ? 1 : -1;
         }
-        int64_t count = 0;
-        if (votes > 0)
-            for (const PairPlan &pp : all)
-                if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) ++count;
-        if (count * 2 >= n_pairs) {
-            const Tiling tl = choose_tiling_uniform(packed, (int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * n_cu);
-            if (tl.cls >= 0)
-                for (PairPlan &pp : all)
-                    if (pp.cls != 255 && ((uint32_t)pp.lx << 16 | (pp.ly & 0xffffu)) == cand) {
-                        pp.cls = (uint8_t)tl.cls;
-                        pp.G = (uint8_t)tl.G;
-                    }
-        }
-    }
-    const double t_plan = now();
-
-    // ---- order: class, then lanes per group (wide first), then long rows first, then file order;
-    // waves end up homogeneous and the longest waves of a launch are dispatched first.
-    // Two stable counting passes (LSD): by ly descending, then by (class, G descending).
-    std::vector<PairPlan> plan;
-    {
-        uint32_t max_ly = 0;
-        size_t n_fill = 0;
-        for (const PairPlan &pp : all)
-            if (pp.cls != 255) {
-                max_ly = std::max(max_ly, pp.ly);
-                ++n_fill;
+        if (votes > 0) {
+            for (Worker &w : wk) w.votes = 0;
+            agx_parallel_for(n_pairs, 16384, [&](int64_t lo, int64_t hi, int tid) {
+                int64_t c = 0;
+                for (int64_t p = lo; p < hi; ++p) c += all[(size_t)p].cls != kClsEmpty && shape(all[(size_t)p]) == cand;
+                wk[(size_t)tid].votes = c;
+            });
+            int64_t count = 0;
+            for (const Worker &w : wk) count += w.votes;
+            if (count * 2 >= n_pairs) {
+                const Tiling tl = choose_tiling_uniform(costs, slots, (int)(cand >> 16), (int)(cand & 0xffffu), count, 4 * n_cu);
+                if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40))
+                    agx_parallel_for(n_pairs, 16384, [&](int64_t lo, int64_t hi, int) {
+                        for (int64_t p = lo; p < hi; ++p) {
+                            PairPlan &pp = all[(size_t)p];
+                            if (pp.cls != kClsEmpty && shape(pp) == cand) {
+                                pp.cls = (uint8_t)tl.cls;
+                                pp.G = (uint8_t)tl.G;
+                            }
+                        }
+                    });
             }
-        std::vector<uint32_t> cnt((size_t)max_ly + 2, 0);
-        for (const PairPlan &pp : all)
-            if (pp.cls != 255) ++cnt[(size_t)(max_ly - pp.ly) + 1];
-        for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-        std::vector<PairPlan> tmp(n_fill);
-        for (const PairPlan &pp : all)
-            if (pp.cls != 255) tmp[cnt[(size_t)(max_ly - pp.ly)]++] = pp;
-        std::vector<uint32_t> cnt2((size_t)kSwNumClasses * 64 + 1, 0);
-        auto bucket = [](const PairPlan &pp) { return (size_t)pp.cls * 64 + (size_t)(64 - pp.G); };
-        for (const PairPlan &pp : tmp) ++cnt2[bucket(pp) + 1];
-        for (size_t k = 1; k < cnt2.size(); ++k) cnt2[k] += cnt2[k - 1];
-        plan.resize(n_fill);
-        for (const PairPlan &pp : tmp) plan[cnt2[bucket(pp)]++] = pp;
+        }
     }
-    std::vector<PairPlan>().swap(all);
-    const double t_sort = now();
+    t_plan = now_ms();
 
-    // ---- form waves and lay out the image (offsets only), then copy the bytes with threads.
-    // Packed kernel: a group carries up to two pairs (slots); the int32 kernel one.
-    const int slots = packed ? 2 : 1;
-    struct Slot {
-        int32_t plan[2]; // indices into plan[], -1 = empty second slot
-    };
-    std::vector<Slot> gslots;
-    gslots.reserve(plan.size() / slots + 16);
-    std::vector<SwWave> waves;
+    // ---- pass C: order = class, then lanes per group (wide first), then long rows first, then file
+    // order; waves end up homogeneous and the longest waves of a launch are dispatched first.
+    // Two stable counting passes (LSD): by ly descending, then by (class, G descending); pairs with an
+    // empty side sort into a trailing bucket and are dropped.
+    {
+        std::vector<PairPlan> tmp;
+        counting_sort(all, tmp, (size_t)longest_long + 2, [&](const PairPlan &pp) { return (size_t)(longest_long + 1 - pp.ly); });
+        std::vector<PairPlan>().swap(all);
+        const size_t n_buckets = (size_t)kSwNumClasses * 64;
+        counting_sort(tmp, plan, n_buckets + 1, [&](const PairPlan &pp) {
+            return pp.cls == kClsEmpty ? n_buckets : (size_t)pp.cls * 64 + (size_t)(64 - pp.G);
+        });
+        while (!plan.empty() && plan.back().cls == kClsEmpty) plan.pop_back();
+    }
+    t_sort = now_ms();
+    } // !planned
+
+    // ---- pass D: every (class, G) bucket is regular, so waves, records and offsets need no scan but the
+    // prefix sum of the image words.
+    std::vector<Bucket> bk;
+    for (size_t i = 0; i < plan.size();) {
+        Bucket q;
+        q.first = i;
+        q.cls = plan[i].cls;
+        q.G = plan[i].G;
+        size_t lo = i, hi = plan.size(); // the run's end by bisection (equal keys are contiguous)
+        while (lo + 1 < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            if (plan[mid].cls == q.cls && plan[mid].G == q.G) lo = mid;
+            else hi = mid;
+        }
+        q.count = lo + 1 - i;
+        i = lo + 1;
+        bk.push_back(q);
+    }
+    size_t n_groups = 0, n_waves = 0;
+    for (Bucket &q : bk) {
+        q.group0 = n_groups;
+        q.n_groups = (q.count + slots - 1) / slots;
+        n_groups += q.n_groups;
+        q.wave0 = n_waves;
+        const size_t per_wave = (size_t)(64 / q.G);
+        q.n_waves = (q.n_groups + per_wave - 1) / per_wave;
+        n_waves += q.n_waves;
+    }
+    std::vector<SwWave> waves(n_waves);
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
-    // word 0.. of the image: a zero block any empty slot points at (x of up to 64*40 bytes)
-    size_t img_dw = packed ? (size_t)kSwPackedMaxShort / 4 + 1 : 0;
-    std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
-    size_t i = 0;
-    while (i < plan.size()) {
-        const int cls = plan[i].cls;
-        ClassLaunch cl;
-        cl.C = kSwClasses[cls];
-        cl.first_wave = (uint32_t)waves.size();
-        while (i < plan.size() && plan[i].cls == cls) {
-            const int G = plan[i].G;
-            const int per_wave = 64 / G;
+    for (const Bucket &q : bk) {
+        if (launches.empty() || launches.back().C != kSwClasses[q.cls]) {
+            ClassLaunch cl;
+            cl.C = kSwClasses[q.cls];
+            cl.first_wave = (uint32_t)q.wave0;
+            launches.push_back(cl);
+        }
+        launches.back().n_waves += (uint32_t)q.n_waves;
+        const size_t per_wave = (size_t)(64 / q.G);
+        for (size_t wl = 0; wl < q.n_waves; ++wl) {
             SwWave w{};
-            w.first_group = (uint32_t)gslots.size();
-            w.G = (uint16_t)G;
-            int n = 0, max_ly = 0;
-            while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
-                Slot sl{{-1, -1}};
-                for (int k = 0; k < slots && i < plan.size() && plan[i].cls == cls && plan[i].G == G; ++k, ++i) {
-                    const PairPlan &pp = plan[i];
-                    const size_t xdw = ((size_t)G * cl.C + 3) / 4 + 1, ydw = ((size_t)pp.ly + 3) / 4;
-                    if (img_dw + xdw + ydw > 0xffffffffull) {
-                        agx_set_error("packed image exceeds 16 GiB; split the batch");
-                        return AGX_E_LIMIT;
-                    }
-                    x_dw[i] = (uint32_t)img_dw;
-                    img_dw += xdw;
-                    y_dw[i] = (uint32_t)img_dw;
-                    img_dw += ydw;
-                    sl.plan[k] = (int32_t)i;
-                    max_ly = std::max(max_ly, (int)pp.ly);
-                }
-                gslots.push_back(sl);
-                ++n;
-            }
-            w.n_groups = (uint16_t)n;
-            w.steps = (uint32_t)(max_ly + G - 1);
-            padded += (int64_t)w.steps * 64 * cl.C * slots;
-            waves.push_back(w);
+            w.first_group = (uint32_t)(q.group0 + wl * per_wave);
+            w.n_groups = (uint16_t)std::min(per_wave, q.n_groups - wl * per_wave);
+            w.G = (uint16_t)q.G;
+            w.steps = plan[q.first + wl * per_wave * slots].ly + (uint32_t)q.G - 1u; // rows are sorted long first
+            waves[q.wave0 + wl] = w;
+            padded += (int64_t)w.steps * 64 * kSwClasses[q.cls] * slots;
         }
-        cl.n_waves = (uint32_t)waves.size() - cl.first_wave;
-        // dispatch order = longest waves first (a wave lasts steps x C; C is the class's): the buckets were
-        // filled widest group first, which leaves narrow groups with long rows for the end of the launch
-        static const bool sort_waves = [] {
-            const char *e = getenv("AGX_SW_SORT_WAVES"); // experiment knob: 0 keeps the bucket order
-            return !(e && e[0] == '0');
-        }();
-        if (sort_waves)
-            std::stable_sort(waves.begin() + cl.first_wave, waves.end(),
+    }
+    // dispatch order = longest waves first (a wave lasts steps x C; C is the class's): the buckets were
+    // filled widest group first, which leaves narrow groups with long rows for the end of the launch
+    static const bool sort_waves = [] {
+        const char *e = agx_tune("AGX_SW_SORT_WAVES");
+        return !(e && e[0] == '0');
+    }();
+    if (sort_waves && !launches.empty())
+        agx_pool_run((int)launches.size(), [&](int k) {
+            const ClassLaunch &cl = launches[(size_t)k];
+            std::stable_sort(waves.begin() + cl.first_wave, waves.begin() + cl.first_wave + cl.n_waves,
                              [](const SwWave &a, const SwWave &b) { return a.steps > b.steps; });
-        launches.push_back(cl);
-    }
-    // group records
-    std::vector<SwGroup> groups1(packed ? 0 : gslots.size());
-    std::vector<SwGroup2> groups2(packed ? gslots.size() : 0);
-    for (size_t k = 0; k < gslots.size(); ++k) {
-        for (int h = 0; h < slots; ++h) {
-            const int32_t pi = gslots[k].plan[h];
-            uint32_t xd = 0, yd = 0, ll = 0, out = (uint32_t)n_pairs; // empty slot: zero block, spare score
-            if (pi >= 0) {
-                const PairPlan &pp = plan[(size_t)pi];
-                xd = x_dw[(size_t)pi];
-                yd = y_dw[(size_t)pi];
-                ll = (uint32_t)pp.lx | (pp.ly << 16);
-                out = pp.pair;
-            }
-            if (packed) {
-                groups2[k].x_dw[h] = xd;
-                groups2[k].y_dw[h] = yd;
-                groups2[k].lx_ly[h] = ll;
-                groups2[k].out[h] = out;
-            } else {
-                groups1[k] = SwGroup{xd, yd, ll, out};
-            }
+        });
+    // image offsets: [x block][y block] per entry in plan order, after the zero block vacant slots point at
+    std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
+    const size_t img0 = packed ? (size_t)kSwPackedMaxShort / 4 + 1 : 0;
+    size_t img_dw = img0;
+    {
+        const int parts = (int)std::min<int64_t>(agx_host_threads(), std::max<int64_t>(1, (int64_t)plan.size() / 16384));
+        std::vector<size_t> part_sum((size_t)parts + 1, 0);
+        const size_t chunk = (plan.size() + parts - 1) / (size_t)parts;
+        auto words = [&](const PairPlan &pp, size_t *xw) {
+            *xw = ((size_t)pp.G * kSwClasses[pp.cls] + 3) / 4 + 1;
+            return *xw + ((size_t)pp.ly + 3) / 4;
+        };
+        agx_pool_run(parts, [&](int t) {
+            const size_t lo = std::min(plan.size(), (size_t)t * chunk), hi = std::min(plan.size(), lo + chunk);
+            size_t s = 0, xw;
+            for (size_t i = lo; i < hi; ++i) s += words(plan[i], &xw);
+            part_sum[(size_t)t + 1] = s;
+        });
+        for (int t = 0; t < parts; ++t) part_sum[(size_t)t + 1] += part_sum[(size_t)t];
+        img_dw = img0 + part_sum[(size_t)parts];
+        if (img_dw > 0xffffffffull) {
+            agx_set_error("packed image exceeds 16 GiB; split the batch");
+            return AGX_E_LIMIT;
         }
-    }
-    const void *groups_data = packed ? (const void *)groups2.data() : (const void *)groups1.data();
-    const size_t groups_bytes = packed ? groups2.size() * sizeof(SwGroup2) : groups1.size() * sizeof(SwGroup);
-
-    struct ImgBuf { // uninitialised storage: every byte is written below (data or zero padding)
-        uint32_t *p = nullptr;
-        size_t n = 0;
-        ~ImgBuf() { free(p); }
-        size_t size() const { return n; }
-        bool empty() const { return n == 0; }
-        const uint32_t *data() const { return p; }
-    } img;
-    img.n = img_dw;
-    img.p = (uint32_t *)malloc(std::max<size_t>(img_dw, 4) * 4);
-    if (!img.p) {
-        agx_set_error("agx_sw_batch_create: out of host memory for the packed image");
-        return AGX_E_NOMEM;
-    }
-    if (packed) memset(img.p, 0, (size_t)kSwPackedMaxShort + 4);
-    agx_parallel_for((int64_t)plan.size(), 2048, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t k = lo; k < hi; ++k) {
-            const PairPlan &pp = plan[(size_t)k];
-            const uint64_t ox = off[2 * (uint64_t)pp.pair + pp.x_is_second];
-            const uint64_t oy = off[2 * (uint64_t)pp.pair + (pp.x_is_second ^ 1)];
-            uint8_t *x = (uint8_t *)(img.p + x_dw[(size_t)k]), *y = (uint8_t *)(img.p + y_dw[(size_t)k]);
-            const size_t xb = (size_t)(y_dw[(size_t)k] - x_dw[(size_t)k]) * 4, yb = (((size_t)pp.ly + 3) / 4) * 4;
-            if (matrix) { // symbol numbers 1..n; 0 stays the padding symbol
-                for (uint32_t c = 0; c < pp.lx; ++c) x[c] = (uint8_t)(matrix->code[bases[ox + c]] + 1);
-                for (uint32_t c = 0; c < pp.ly; ++c) y[c] = (uint8_t)(matrix->code[bases[oy + c]] + 1);
-            } else {
-                memcpy(x, bases + ox, pp.lx);
-                memcpy(y, bases + oy, pp.ly);
+        agx_pool_run(parts, [&](int t) {
+            const size_t lo = std::min(plan.size(), (size_t)t * chunk), hi = std::min(plan.size(), lo + chunk);
+            size_t at = img0 + part_sum[(size_t)t], xw;
+            for (size_t i = lo; i < hi; ++i) {
+                const size_t tot = words(plan[i], &xw);
+                x_dw[i] = (uint32_t)at;
+                y_dw[i] = (uint32_t)(at + xw);
+                at += tot;
             }
-            memset(x + pp.lx, 0, xb - pp.lx);
-            memset(y + pp.ly, 0, yb - pp.ly);
-        }
-    });
+        });
+    }
+    const double t_waves = now_ms();
 
-    const double t_pack = now();
-    // ---- device image
-    agx_sw_batch *b = new agx_sw_batch();
-    b->ctx = ctx;
-    b->n_pairs = n_pairs;
+    // ---- group records, written straight into pinned staging when there is a device
+    const size_t groups_bytes = n_groups * (packed ? sizeof(SwGroup2) : sizeof(SwGroup)), waves_bytes = waves.size() * sizeof(SwWave);
+    std::vector<uint8_t> groups_host; // plan-only: no pinned memory without a device
+    void *groups_data = nullptr;
+    if (ctx) {
+        rc = h_groups.alloc(ctx, groups_bytes);
+        if (!rc) rc = h_waves.alloc(ctx, waves_bytes);
+        if (!rc) rc = h_flag.alloc(ctx, 2 * sizeof(uint32_t));
+        if (rc) return rc;
+        groups_data = h_groups.p;
+        if (waves_bytes) memcpy(h_waves.p, waves.data(), waves_bytes);
+    } else {
+        groups_host.resize(groups_bytes);
+        groups_data = groups_host.data();
+    }
+    for (const Bucket &q : bk)
+        agx_parallel_for((int64_t)q.n_groups, 8192, [&](int64_t a, int64_t z, int) {
+            for (int64_t g = a; g < z; ++g)
+                for (int h = 0; h < slots; ++h) {
+                    const size_t j = (size_t)g * slots + h;
+                    uint32_t xd = 0, yd = 0, ll = 0, outi = (uint32_t)n_pairs; // vacant slot: zero block, spare score
+                    if (j < q.count) {
+                        const PairPlan &pp = plan[q.first + j];
+                        xd = x_dw[q.first + j];
+                        yd = y_dw[q.first + j];
+                        ll = (uint32_t)pp.lxo | (pp.ly << 16);
+                        outi = pp.pair;
+                    }
+                    if (packed) {
+                        SwGroup2 &r = reinterpret_cast<SwGroup2 *>(groups_data)[q.group0 + (size_t)g];
+                        r.x_dw[h] = xd;
+                        r.y_dw[h] = yd;
+                        r.lx_ly[h] = ll;
+                        r.out[h] = outi;
+                    } else
+                        reinterpret_cast<SwGroup *>(groups_data)[q.group0 + (size_t)g] = SwGroup{xd, yd, ll, outi};
+                }
+        });
+    const double t_records = now_ms();
+
     b->launches = launches;
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
     b->info.padded_cells = padded;
-    b->packed = packed;
-    b->biased = biased;
-    b->matrix = matrix != nullptr;
-    b->prm = prm;
-    b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + waves.size() * sizeof(SwWave));
+    b->info.input_bytes = (int64_t)(img_dw * 4 + groups_bytes + waves_bytes);
     b->info.n_launches = (int32_t)launches.size();
     b->info.n_waves = (int32_t)waves.size();
     if (!ctx) { // planning only
         *out = b;
+        b = nullptr;
         return AGX_OK;
     }
-    rc = b->img.alloc(img.size() * 4);
-    if (!rc) rc = b->groups.alloc(groups_bytes);
-    if (!rc) rc = b->waves.alloc(waves.size() * sizeof(SwWave));
-    if (!rc && matrix) rc = b->table.alloc(table.size() * sizeof(int16_t));
-    if (!rc) rc = b->scores.alloc(((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of empty packed halves
-    if (rc) {
-        agx_sw_batch_destroy(b);
-        return rc;
+
+    // ---- device image: records up, image built and checked by the pack kernel, all on the copy stream
+    if (uploader.joinable()) uploader.join();
+    if (up_rc) {
+        agx_set_error("%s", up_err);
+        return up_rc;
     }
+    const double t_joined = now_ms();
+    rc = b->img.alloc(ctx, std::max<size_t>(img_dw, 4) * 4);
+    if (!rc) rc = b->groups.alloc(ctx, groups_bytes);
+    if (!rc) rc = b->waves.alloc(ctx, waves_bytes);
+    if (!rc && matrix) rc = b->table.alloc(ctx, table.size() * sizeof(int16_t));
+    if (!rc) rc = b->scores.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of vacant packed halves
+    if (rc) return rc;
+    hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
-    if (!img.empty()) e = hipMemcpy(b->img.p, img.data(), img.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && groups_bytes)
-        e = hipMemcpy(b->groups.p, groups_data, groups_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && !waves.empty())
-        e = hipMemcpy(b->waves.p, waves.data(), waves.size() * sizeof(SwWave), hipMemcpyHostToDevice);
-    if (e == hipSuccess && matrix) e = hipMemcpy(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (groups_bytes) e = hipMemcpyAsync(b->groups.p, h_groups.p, groups_bytes, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess && waves_bytes) e = hipMemcpyAsync(b->waves.p, h_waves.p, waves_bytes, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess && matrix)
+        e = hipMemcpyAsync(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice, cs);
     // pairs with an empty side are never touched by a kernel: their score is this zero
-    if (e == hipSuccess) e = hipMemset(b->scores.p, 0, b->scores.bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(b->scores.p, 0, b->scores.bytes, cs);
+    if (e == hipSuccess && packed) e = hipMemsetAsync(b->img.p, 0, (size_t)kSwPackedMaxShort + 4, cs);
+    uint32_t *flag = (uint32_t *)h_flag.p;
+    flag[0] = 0;
+    flag[1] = 0xffffffffu;
+    if (e == hipSuccess && n_groups) {
+        if (agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base, b->groups.p,
+                               (uint32_t)n_groups, (uint32_t)n_pairs, (uint32_t *)b->img.p, (const uint8_t *)d_code.p,
+                               (uint32_t *)d_flag.p, n_cu, cs)) {
+            agx_set_error("sw_pack launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return AGX_E_HIP;
+        }
+        e = hipMemcpyAsync(flag, d_flag.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(cs); // blocking by contract; the staging buffers are free again
     if (e != hipSuccess) {
         agx_set_error("agx_sw_batch_create: upload -> %s", hipGetErrorString(e));
-        agx_sw_batch_destroy(b);
         return AGX_E_HIP;
     }
+    if (flag[0]) {
+        if (matrix)
+            agx_set_error("pair %u contains a byte outside the substitution matrix's alphabet", flag[1]);
+        else
+            agx_set_error("pair %u contains byte 0x00, which is reserved as the padding symbol", flag[1]);
+        return AGX_E_SYMBOL;
+    }
     if (trace)
-        fprintf(stderr, "[agx_sw_batch_create] %lld pairs: plan %.2f ms, sort %.2f ms, pack %.2f ms, alloc+H2D %.2f ms (%.1f MB)\n",
-                (long long)n_pairs, t_plan - t_begin, t_sort - t_plan, t_pack - t_sort, now() - t_pack, img.size() * 4 / 1e6);
+        fprintf(stderr,
+                "[agx_sw_batch_create] %lld pairs: pass A %.2f ms | tiling %.2f, sort %.2f, waves %.2f, records %.2f | waited %.2f ms more "
+                "for the upload of %.1f MB | device pack + sync %.2f ms\n",
+                (long long)n_pairs, t_pass_a - t_begin, t_plan - t_pass_a, t_sort - t_plan, t_waves - t_sort, t_records - t_waves,
+                t_joined - t_records, raw_bytes / 1e6, now_ms() - t_joined);
     *out = b;
+    b = nullptr;
     return AGX_OK;
 }
 
@@ -721,17 +1038,20 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     for (auto it = b->launches.rbegin(); it != b->launches.rend(); ++it) {
         const ClassLaunch &cl = *it;
         hipStream_t st = fan.stream(k++);
-        const int r = b->matrix
-                          ? agx_sw_mat_launch_class(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
-                                                    (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                                    (int32_t *)b->scores.p, (const int16_t *)b->table.p, st)
-                          : b->packed
-                          ? (b->biased ? agx_sw_pk2_launch_class : agx_sw_pk_launch_class)(cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup2 *)b->groups.p,
-                                                   (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves,
-                                                   (int32_t *)b->scores.p, st)
-                          : (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(
-                                cl.C, b->prm, (const uint32_t *)b->img.p, (const SwGroup *)b->groups.p,
-                                (const SwWave *)b->waves.p + cl.first_wave, cl.n_waves, (int32_t *)b->scores.p, st);
+        const uint32_t *img = (const uint32_t *)b->img.p;
+        const SwWave *wv = (const SwWave *)b->waves.p + cl.first_wave;
+        int32_t *scores = (int32_t *)b->scores.p;
+        int r;
+        if (b->matrix)
+            r = agx_sw_mat_launch_class(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
+                                        (const int16_t *)b->table.p, st);
+        else if (b->family == 2)
+            r = agx_sw_pk2_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+        else if (b->family == 1)
+            r = agx_sw_pk_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+        else
+            r = (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv,
+                                                                             cl.n_waves, scores, st);
         if (r) {
             agx_set_error("sw_fill<%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
@@ -752,9 +1072,24 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
-    AGX_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (b->n_pairs)
-        AGX_HIP(hipMemcpy(scores, b->scores.p, (size_t)b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (b->n_pairs == 0) {
+        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+        return AGX_OK;
+    }
+    // through pinned staging on the launch stream: one DMA right behind the last kernel, then a host copy
+    // (a pageable destination makes the runtime stage the copy itself, later and slower)
+    const size_t bytes = (size_t)b->n_pairs * sizeof(int32_t);
+    PinBuf stage;
+    rc = stage.alloc(b->ctx, bytes);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(stage.p, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
+    if (e == hipSuccess) memcpy(scores, stage.p, bytes);
+    stage.release();
+    if (e != hipSuccess) {
+        agx_set_error("agx_sw_batch_scores: %s", hipGetErrorString(e));
+        return AGX_E_HIP;
+    }
     return AGX_OK;
 }
 
@@ -774,16 +1109,88 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
     agx_sw_batch *b = nullptr;
     int rc = agx_sw_batch_create(ctx, bases, off, len, n_pairs, &b);
     if (rc) return rc;
-    const bool trace = getenv("AGX_TRACE_CREATE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
     rc = agx_sw_batch_launch(b);
-    const double t1 = now();
     if (!rc) rc = agx_sw_batch_scores(b, scores);
-    const double t2 = now();
-    agx_sw_batch_destroy(b);
-    if (trace) fprintf(stderr, "[agx_sw_score] launch %.2f ms, wait+D2H %.2f ms, destroy %.2f ms\n", t1 - t0, t2 - t1, now() - t2);
+    agx_sw_batch_destroy(b); // its buffers return to the context's pools for the next call
     return rc;
+}
+
+int agx_sw_shard_cuts(const uint32_t *len, int64_t n_pairs, int n_shards, int64_t *cut)
+{
+    if (n_pairs < 0 || n_shards < 1 || !cut || (n_pairs > 0 && !len)) {
+        agx_set_error("agx_sw_shard_cuts: bad arguments");
+        return AGX_E_ARG;
+    }
+    // contiguous shards balanced by cells
+    for (int d = 0; d <= n_shards; ++d) cut[d] = n_pairs;
+    cut[0] = 0;
+    double total = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) total += (double)len[2 * p] * len[2 * p + 1] + 1.0;
+    double acc = 0;
+    int d = 1;
+    for (int64_t p = 0; p < n_pairs && d < n_shards; ++p) {
+        acc += (double)len[2 * p] * len[2 * p + 1] + 1.0;
+        while (d < n_shards && acc >= total * d / n_shards) cut[d++] = p + 1;
+    }
+    return AGX_OK;
+}
+
+int agx_sw_score_devices(const int *devices, int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
+                         int64_t n_pairs, int32_t *scores)
+{
+    AGX_GUARD_BEGIN
+    const int avail = agx_device_count();
+    if (avail <= 0) {
+        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
+        return AGX_E_NODEVICE;
+    }
+    if (!devices || n_devices < 1 || n_devices > 1024 || n_pairs < 0 || (n_pairs > 0 && (!off || !len || !scores))) {
+        agx_set_error("agx_sw_score_devices: bad arguments");
+        return AGX_E_ARG;
+    }
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= avail) {
+            agx_set_error("agx_sw_score_devices: device %d out of range [0,%d)", devices[k], avail);
+            return AGX_E_NODEVICE;
+        }
+    // results land in disjoint slices of the caller's array: no exchange step
+    std::vector<int64_t> cut((size_t)n_devices + 1);
+    int rc = agx_sw_shard_cuts(len, n_pairs, n_devices, cut.data());
+    if (rc) return rc;
+    std::vector<int> rcs((size_t)n_devices, AGX_OK), slot((size_t)n_devices, 0);
+    for (int k = 0; k < n_devices; ++k) // shards sharing a device get contexts of their own
+        for (int j = 0; j < k; ++j) slot[(size_t)k] += devices[j] == devices[k];
+    std::vector<std::string> errs((size_t)n_devices);
+    auto shard = [&](int k) {
+        const int64_t lo = cut[(size_t)k], hi = cut[(size_t)k + 1];
+        if (hi <= lo) return;
+        int r;
+        try {
+            agx_ctx *c = nullptr;
+            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c); // created once per process: pools stay warm
+            if (!r) r = agx_sw_score(c, bases, off + 2 * lo, len + 2 * lo, hi - lo, scores + lo);
+        } catch (const std::exception &ex) {
+            agx_set_error("shard %d: %s", k, ex.what());
+            r = AGX_E_NOMEM;
+        }
+        if (r) errs[(size_t)k] = agx_last_error();
+        rcs[(size_t)k] = r;
+    };
+    if (n_devices == 1)
+        shard(0);
+    else {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_devices; ++k) th.emplace_back(shard, k);
+        shard(0);
+        for (auto &t : th) t.join();
+    }
+    for (int k = 0; k < n_devices; ++k)
+        if (rcs[(size_t)k]) {
+            agx_set_error("device %d: %s", devices[k], errs[(size_t)k].c_str());
+            return rcs[(size_t)k];
+        }
+    return AGX_OK;
+    AGX_GUARD_END("agx_sw_score_devices")
 }
 
 int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
@@ -794,48 +1201,11 @@ int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off,
         agx_set_error("no HIP device is visible (this library has no CPU fallback)");
         return AGX_E_NODEVICE;
     }
-    // AGX_MULTI_OVERSUBSCRIBE=1 (tests on a one-GPU box): keep the requested shard count, shard k runs on device k % avail
-    const bool oversub = getenv("AGX_MULTI_OVERSUBSCRIBE") != nullptr && n_devices > 0 && n_devices <= 64;
-    if (n_devices <= 0 || (n_devices > avail && !oversub)) n_devices = avail;
-    if (n_pairs < 0 || (n_pairs > 0 && (!off || !len || !scores))) {
-        agx_set_error("agx_sw_score_multi: bad arguments");
-        return AGX_E_ARG;
-    }
-    // contiguous shards balanced by cells; results land in disjoint slices
-    std::vector<int64_t> cut(n_devices + 1, n_pairs);
-    {
-        double total = 0;
-        for (int64_t p = 0; p < n_pairs; ++p) total += (double)len[2 * p] * len[2 * p + 1] + 1.0;
-        double acc = 0;
-        int d = 1;
-        cut[0] = 0;
-        for (int64_t p = 0; p < n_pairs && d < n_devices; ++p) {
-            acc += (double)len[2 * p] * len[2 * p + 1] + 1.0;
-            while (d < n_devices && acc >= total * d / n_devices) cut[d++] = p + 1;
-        }
-    }
-    std::vector<int> rcs(n_devices, AGX_OK);
-    std::vector<std::string> errs(n_devices);
-    std::vector<std::thread> th;
-    for (int d = 0; d < n_devices; ++d) {
-        th.emplace_back([&, d]() {
-            const int64_t lo = cut[d], hi = cut[d + 1];
-            if (hi <= lo) return;
-            agx_ctx *c = nullptr;
-            int rc = agx_ctx_create(d % avail, &c);
-            if (!rc) rc = agx_sw_score(c, bases, off + 2 * lo, len + 2 * lo, hi - lo, scores + lo);
-            if (rc) errs[d] = agx_last_error();
-            agx_ctx_destroy(c);
-            rcs[d] = rc;
-        });
-    }
-    for (auto &t : th) t.join();
-    for (int d = 0; d < n_devices; ++d)
-        if (rcs[d]) {
-            agx_set_error("device %d: %s", d, errs[d].c_str());
-            return rcs[d];
-        }
-    return AGX_OK;
+    if (n_devices <= 0 || n_devices > avail) n_devices = avail;
+    n_devices = std::min(n_devices, 1024);
+    int devs[1024];
+    for (int k = 0; k < n_devices; ++k) devs[k] = k;
+    return agx_sw_score_devices(devs, n_devices, bases, off, len, n_pairs, scores);
 }
 
 } // extern "C"

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 // One alignment pair = one group of G lanes.  Offsets are in 4-byte words into the packed
@@ -10,8 +11,8 @@
 struct SwGroup {
     uint32_t x_dw;
     uint32_t y_dw;
-    uint32_t lx_ly; // lx | ly << 16
-    uint32_t out;   // index into scores[]
+    uint32_t lx_ly; // lx | (1 = the pair's SECOND sequence is the shorter one) << 15 | ly << 16; the fills read ly only
+    uint32_t out;   // index into scores[] = the caller's pair number
 };
 
 // Scoring, as the kernels consume it (built by the host from agx_sw_scoring).  With z = H + gf the
@@ -64,12 +65,20 @@ static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
 static const double kSwClassCost[] = {1.373, 1.250, 1.178, 1.138, 1.112, 1.080, 1.051, 1.033, 1.025, 1.022, 1.014, 1.014, 1.011, 1.007, 1.007, 1.004, 1.004, 1.004, 1.000, 1.6, 2.2, 4.0};
 // same for the packed int16 kernel
 static const double kSwPkClassCost[] = {1.543, 1.358, 1.278, 1.210, 1.173, 1.136, 1.111, 1.086, 1.068, 1.037, 1.025, 1.025, 1.019, 1.012, 1.006, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
+// and for its biased formulation (agx_sw_pk2_kernel.hip; tools/cal_sw_pk.py, profiles/r02_cal_sw_pk2.log)
+static const double kSwPk2ClassCost[] = {1.571, 1.383, 1.285, 1.228, 1.166, 1.128, 1.114, 1.083, 1.070, 1.050, 1.032, 1.035, 1.025, 1.025, 1.016, 1.019, 1.009, 1.006, 1.000, 0, 0, 0};
 
 // substitution-matrix mode: symbol numbers 1..32 in the image, 0 = padding; the device table is
 // kSwMatDim x kSwMatDim int16 entries score - (gap_open + gap_extend)
 constexpr int kSwMatDim = 33;
 int agx_sw_mat_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, const int16_t *table, hipStream_t s);
+// Builds the image the records describe from the caller's raw arrays, on the device (agx_sw_pack_kernel.hip).
+// raw = bases[base ..), off = the caller's offsets (absolute), groups = SwGroup (slots 1) or SwGroup2 (slots 2)
+// records, code = substitution-matrix byte map or NULL, flag[2] = {offending pairs, smallest of them}.
+int agx_sw_pack_launch(bool matrix, int slots, const uint8_t *raw, const uint64_t *off, uint64_t base, const void *groups,
+                       uint32_t n_groups, uint32_t n_pairs, uint32_t *img, const uint8_t *code, uint32_t *flag, int n_cu,
+                       hipStream_t s);
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,

@@ -276,29 +276,82 @@ static size_t next_token(const char **s, const char **tok)
     return (size_t)(p - *tok);
 }
 
-int agx_phmm_text_read(const char *path, agx_phmm_text **out)
+/*
+ * The reference's batch loop (antidiagsPairHMM.c:371-433,484-489) as a reader that hands out whole
+ * regions: every next() returns the regions up to the first one that brings the chunk to max_pairs
+ * pairs (at least one region), as a fresh agx_phmm_text the caller frees.  State that the reference
+ * keeps across loop turns stays in the reader: nr / nh survive a malformed header line (sscanf leaves
+ * them untouched, :378).
+ */
+struct agx_phmm_reader {
+    FILE *f;
+    char *line;
+    int nr, nh;
+    int finished;
+    uint32_t regions_done; /* complete regions handed out so far (for error messages) */
+};
+
+void agx_phmm_reader_close(agx_phmm_reader *r)
+{
+    if (!r) return;
+    if (r->f) fclose(r->f);
+    free(r->line);
+    free(r);
+}
+
+int agx_phmm_reader_open(const char *path, agx_phmm_reader **out)
 {
     if (!out || !path) {
-        agx_set_error("agx_phmm_text_read: null argument");
+        agx_set_error("agx_phmm_reader_open: null argument");
         return AGX_E_ARG;
     }
     *out = NULL;
-    FILE *f = fopen(path, "r");
-    if (!f) {
+    agx_phmm_reader *r = (agx_phmm_reader *)calloc(1, sizeof *r);
+    if (!r) {
+        agx_set_error("agx_phmm_reader_open: out of memory");
+        return AGX_E_NOMEM;
+    }
+    r->line = (char *)malloc(PHMM_LINE);
+    r->f = fopen(path, "r");
+    if (!r->f) {
         agx_set_error("Error opening input file_r: %s", strerror(errno));
+        agx_phmm_reader_close(r);
         return AGX_E_IO;
     }
+    if (!r->line) {
+        agx_set_error("agx_phmm_reader_open: out of memory");
+        agx_phmm_reader_close(r);
+        return AGX_E_NOMEM;
+    }
+    setvbuf(r->f, NULL, _IOFBF, (size_t)1 << 20);
+    *out = r;
+    return AGX_OK;
+}
+
+int agx_phmm_reader_done(const agx_phmm_reader *r) { return !r || r->finished; }
+
+int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **out)
+{
+    if (!r || !out) {
+        agx_set_error("agx_phmm_reader_next: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
     int rc = AGX_E_NOMEM;
     phmm_text_impl *m = (phmm_text_impl *)calloc(1, sizeof *m);
-    char *line = (char *)malloc(PHMM_LINE);
+    char *line = r->line;
     char **rl = NULL;
-    int nr = 0, nh = 0; /* sscanf leaves them untouched on a malformed header (:378) */
+    int nr = r->nr, nh = r->nh;
     uint64_t z64 = 0;
     uint32_t z32 = 0;
-    if (!m || !line) goto done;
-    if (buf_put(&m->roff, &z64, 8) || buf_put(&m->hoff, &z64, 8) || buf_put(&m->rreg, &z32, 4) || buf_put(&m->hreg, &z32, 4)) goto done;
     uint32_t n_reads = 0, n_haps = 0, n_regions = 0;
-    while (fgets(line, PHMM_LINE, f)) { /* :375 */
+    if (!m) goto done;
+    if (buf_put(&m->roff, &z64, 8) || buf_put(&m->hoff, &z64, 8) || buf_put(&m->rreg, &z32, 4) || buf_put(&m->hreg, &z32, 4)) goto done;
+    while (!r->finished && (n_regions == 0 || m->pub.n_pairs < max_pairs)) {
+        if (!fgets(line, PHMM_LINE, r->f)) { /* :375 */
+            r->finished = 1;
+            break;
+        }
         m->pub.n_regions_seen++;
         sscanf(line, "%d %d", &nr, &nh);
         if (nr < 0) nr = 0;
@@ -309,7 +362,7 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
         if (!rl) goto done;
         int got_r = 0, got_h = 0, bad = 0;
         for (; got_r < nr; got_r++) {
-            if (!fgets(line, PHMM_LINE, f)) break;
+            if (!fgets(line, PHMM_LINE, r->f)) break;
             line[strcspn(line, "\n")] = 0; /* :417 */
             rl[got_r] = strdup(line);
             if (!rl[got_r]) goto done;
@@ -317,7 +370,7 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
         const size_t hb_mark = m->hb.n, hoff_mark = m->hoff.n;
         if (got_r == nr) {
             for (; got_h < nh; got_h++) {
-                if (!fgets(line, PHMM_LINE, f)) break;
+                if (!fgets(line, PHMM_LINE, r->f)) break;
                 line[strcspn(line, "\n")] = 0; /* :399 */
                 size_t n = strlen(line);
                 if (buf_put(&m->hb, line, n)) goto done;
@@ -335,7 +388,7 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
         for (int i = 0; i < nr && !bad; i++) {
             size_t sl = strlen(rl[i]);
             if (sl < 4) { /* (strlen-4)/5 underflows in the reference (:418) */
-                agx_set_error("region %u, read %d: line too short to hold five fields", n_regions + 1, i);
+                agx_set_error("region %u, read %d: line too short to hold five fields", r->regions_done + n_regions + 1, i);
                 rc = AGX_E_IO;
                 goto done;
             }
@@ -345,7 +398,7 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
             for (int k = 0; k < 5; k++) tl[k] = next_token(&p, &tok[k]);
             for (int k = 0; k < 5; k++)
                 if (tl[k] < n) {
-                    agx_set_error("region %u, read %d: field %d shorter than the read length %zu", n_regions + 1, i, k, n);
+                    agx_set_error("region %u, read %d: field %d shorter than the read length %zu", r->regions_done + n_regions + 1, i, k, n);
                     rc = AGX_E_IO;
                     goto done;
                 }
@@ -361,6 +414,7 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
         if (bad) {
             m->rb.n = m->qb.n = m->qi.n = m->qd.n = m->qg.n = rb_mark;
             m->roff.n = roff_mark;
+            r->finished = 1;
             break;
         }
         n_reads += (uint32_t)nr;
@@ -382,19 +436,36 @@ int agx_phmm_text_read(const char *path, agx_phmm_text **out)
     m->pub.desc.region_read = (const uint32_t *)m->rreg.p;
     m->pub.desc.region_hap = (const uint32_t *)m->hreg.p;
     m->pub.desc.n_regions = n_regions;
+    r->regions_done += n_regions;
     rc = AGX_OK;
 done:
-    fclose(f);
-    free(line);
+    r->nr = nr;
+    r->nh = nh;
     if (rl) {
         for (int i = 0; i < nr; i++) free(rl[i]);
         free(rl);
     }
-    if (rc == AGX_E_NOMEM) agx_set_error("agx_phmm_text_read: out of memory");
+    if (rc == AGX_E_NOMEM) agx_set_error("agx_phmm_reader_next: out of memory");
     if (rc != AGX_OK) {
         agx_phmm_text_free(m ? &m->pub : NULL);
         m = NULL;
+        r->finished = 1;
     }
     *out = m ? &m->pub : NULL;
+    return rc;
+}
+
+int agx_phmm_text_read(const char *path, agx_phmm_text **out)
+{
+    if (!out || !path) {
+        agx_set_error("agx_phmm_text_read: null argument");
+        return AGX_E_ARG;
+    }
+    *out = NULL;
+    agx_phmm_reader *r = NULL;
+    int rc = agx_phmm_reader_open(path, &r);
+    if (rc != AGX_OK) return rc;
+    rc = agx_phmm_reader_next(r, INT64_MAX, out);
+    agx_phmm_reader_close(r);
     return rc;
 }

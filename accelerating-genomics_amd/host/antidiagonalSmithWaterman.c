@@ -3,11 +3,14 @@
  * (smithWaterman/antidiagonalSmithWaterman.c:189-358): same argument, same input format, same
  * stdout (`line_num: N`, one `Score: s` per pair in file order, `elapsed t`), same exit codes.
  * The per-pair anti-diagonal fill (:254-347) runs on the GPU through libagx (include/agx.h);
- * there is no CPU path.  AGX_NUM_DEVICES=n shards the pairs over n GPUs (default 1, 0 = all).
+ * there is no CPU path.
+ *   AGX_NUM_DEVICES = n   shard the pairs over GPUs 0..n-1 (default 1, 0 = all visible)
+ *   AGX_DEVICES = 0,0,1   explicit list, one shard per entry (an ordinal may repeat)
+ *   AGX_CLI_CHUNK_PAIRS   pairs per pipeline step (default 262144)
  *
- * Streaming: a parser thread reads the file in chunks of AGX_CLI_CHUNK_PAIRS
- * pairs (default 262144) while the main thread packs, scores and prints the previous chunk, and
- * the HIP runtime comes up on a third thread while the first chunk is parsed.
+ * Streaming: three stages on three threads -- the parser reads chunk k+1 while the
+ * main thread has chunk k scored on the device and the printer formats and writes chunk k-1 -- and the
+ * HIP runtime comes up on a fourth while the first chunk is parsed.
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -16,6 +19,7 @@
 #include <sys/time.h>
 
 #include "agx.h"
+#include "agx_pipe.h"
 
 static double seconds(void)
 {
@@ -24,55 +28,65 @@ static double seconds(void)
     return (double)tp.tv_sec + (double)tp.tv_usec * 1.e-6;
 }
 
-/* two-slot queue between the parser thread and main */
 typedef struct {
     agx_sw_reader *reader;
     int64_t chunk_pairs;
-    pthread_mutex_t mu;
-    pthread_cond_t cv;
-    agx_sw_text *slot[2];
-    int count, closed, rc;
+    agx_pipe q;
+    int rc;
     char err[512];
-} pipe_t;
+} parse_stage;
 
 static void *parser_main(void *arg)
 {
-    pipe_t *q = (pipe_t *)arg;
-    int rc = AGX_OK;
-    while (rc == AGX_OK && !agx_sw_reader_done(q->reader)) {
+    parse_stage *s = (parse_stage *)arg;
+    while (!agx_sw_reader_done(s->reader)) {
         agx_sw_text *t = NULL;
-        rc = agx_sw_reader_next(q->reader, q->chunk_pairs, &t);
-        pthread_mutex_lock(&q->mu);
+        const int rc = agx_sw_reader_next(s->reader, s->chunk_pairs, &t);
         if (rc != AGX_OK) {
-            q->rc = rc;
-            snprintf(q->err, sizeof q->err, "%s", agx_last_error());
-        } else {
-            while (q->count == 2) pthread_cond_wait(&q->cv, &q->mu);
-            q->slot[q->count++] = t;
-            pthread_cond_broadcast(&q->cv);
+            s->rc = rc;
+            snprintf(s->err, sizeof s->err, "%s", agx_last_error());
+            break;
         }
-        pthread_mutex_unlock(&q->mu);
+        agx_pipe_push(&s->q, t);
     }
-    pthread_mutex_lock(&q->mu);
-    q->closed = 1;
-    pthread_cond_broadcast(&q->cv);
-    pthread_mutex_unlock(&q->mu);
+    agx_pipe_close(&s->q);
     return NULL;
 }
 
-static agx_sw_text *pipe_pop(pipe_t *q)
+typedef struct {
+    agx_sw_text *text; /* for n_pairs and the dangling line */
+    int32_t *scores;
+} scored_chunk;
+
+typedef struct {
+    agx_pipe q;
+    double t_print;
+} print_stage;
+
+static void *printer_main(void *arg)
 {
-    pthread_mutex_lock(&q->mu);
-    while (q->count == 0 && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
-    agx_sw_text *t = NULL;
-    if (q->count) {
-        t = q->slot[0];
-        q->slot[0] = q->slot[1];
-        q->count--;
-        pthread_cond_broadcast(&q->cv);
+    print_stage *s = (print_stage *)arg;
+    for (;;) {
+        scored_chunk *c = (scored_chunk *)agx_pipe_pop(&s->q);
+        if (!c) break;
+        const double ta = seconds();
+        /* "Score: " + at most 11 characters + newline per pair, formatted into one block */
+        const int64_t n = c->text->n_pairs;
+        char *buf = (char *)malloc((size_t)n * 20 + 16);
+        if (buf) {
+            size_t at = 0;
+            for (int64_t p = 0; p < n; p++) at += (size_t)sprintf(buf + at, "Score: %d\n", c->scores[p]); /* :348 */
+            fwrite(buf, 1, at, stdout);
+            free(buf);
+        } else
+            for (int64_t p = 0; p < n; p++) printf("Score: %d\n", c->scores[p]);
+        if (c->text->dangling) printf("%s", c->text->dangling); /* :225 */
+        s->t_print += seconds() - ta;
+        free(c->scores);
+        agx_sw_text_free(c->text);
+        free(c);
     }
-    pthread_mutex_unlock(&q->mu);
-    return t;
+    return NULL;
 }
 
 typedef struct {
@@ -97,13 +111,15 @@ int main(int argc, char *argv[])
     }
     const int trace = getenv("AGX_TRACE_CLI") != NULL;
     const double tr0 = seconds();
+    int devices[64];
+    int n_dev = agx_parse_devices(getenv("AGX_DEVICES"), devices, 64);
     const char *nd = getenv("AGX_NUM_DEVICES");
-    const int n_dev = nd ? atoi(nd) : 1;
+    const int n_multi = nd ? atoi(nd) : 1; /* used when AGX_DEVICES is not set */
     const char *cp = getenv("AGX_CLI_CHUNK_PAIRS");
-    pipe_t q;
-    memset(&q, 0, sizeof q);
-    q.chunk_pairs = cp && atoll(cp) > 0 ? atoll(cp) : 262144;
-    int rc = agx_sw_reader_open(argv[1], 0, &q.reader);
+    parse_stage ps;
+    memset(&ps, 0, sizeof ps);
+    ps.chunk_pairs = cp && atoll(cp) > 0 ? atoll(cp) : 262144;
+    int rc = agx_sw_reader_open(argv[1], 0, &ps.reader);
     if (rc != AGX_OK) {
         if (strcmp(agx_last_error(), "file is empty") == 0) { /* :205-208 */
             printf("file is empty");
@@ -112,23 +128,29 @@ int main(int argc, char *argv[])
         fprintf(stderr, "%s\n", agx_last_error()); /* perror("Error opening file"), :196-199 */
         exit(EXIT_FAILURE);
     }
-    pthread_mutex_init(&q.mu, NULL);
-    pthread_cond_init(&q.cv, NULL);
-    pthread_t parser, warmer;
+    agx_pipe_init(&ps.q, 2);
+    print_stage pr;
+    memset(&pr, 0, sizeof pr);
+    agx_pipe_init(&pr.q, 2);
+    pthread_t parser, warmer, printer;
     warm_t warm;
     memset(&warm, 0, sizeof warm);
-    if (pthread_create(&parser, NULL, parser_main, &q) || pthread_create(&warmer, NULL, warm_main, &warm)) {
+    const int single = n_dev == 0 && n_multi == 1; /* one context of our own, warmed while the parser starts */
+    printf("line_num: %d\n", agx_sw_reader_line_num(ps.reader)); /* :210 */
+    fflush(stdout);
+    if (pthread_create(&parser, NULL, parser_main, &ps) || pthread_create(&printer, NULL, printer_main, &pr) ||
+        (single && pthread_create(&warmer, NULL, warm_main, &warm))) {
         fprintf(stderr, "antidiagonalSmithWaterman: cannot start threads\n");
         return EXIT_FAILURE;
     }
-    printf("line_num: %d\n", agx_sw_reader_line_num(q.reader)); /* :210 */
     const double t0 = seconds(); /* the reference's clock also spans reading + scoring + printing */
-    int warm_joined = 0;
-    double t_wait = 0, t_score = 0, t_print = 0;
+    int warm_joined = !single;
+    double t_wait = 0, t_score = 0;
     int64_t n_chunks = 0;
+    int status = 0;
     for (;;) {
         double ta = seconds();
-        agx_sw_text *t = pipe_pop(&q);
+        agx_sw_text *t = (agx_sw_text *)agx_pipe_pop(&ps.q);
         t_wait += seconds() - ta;
         if (!t) break;
         if (!warm_joined) {
@@ -136,41 +158,52 @@ int main(int argc, char *argv[])
             warm_joined = 1;
             if (warm.rc != AGX_OK) {
                 fprintf(stderr, "antidiagonalSmithWaterman: %s\n", warm.err);
-                return EXIT_FAILURE;
+                status = EXIT_FAILURE;
             }
         }
         ta = seconds();
+        scored_chunk *c = (scored_chunk *)calloc(1, sizeof *c);
         int32_t *scores = (int32_t *)malloc(sizeof(int32_t) * (size_t)(t->n_pairs ? t->n_pairs : 1));
-        if (!scores) {
+        if (!c || !scores) {
             fprintf(stderr, "out of memory\n");
-            return EXIT_FAILURE;
+            status = EXIT_FAILURE;
         }
-        rc = n_dev == 1 ? agx_sw_score(warm.ctx, t->bases, t->off, t->len, t->n_pairs, scores)
-                        : agx_sw_score_multi(n_dev, t->bases, t->off, t->len, t->n_pairs, scores);
-        if (rc != AGX_OK) {
-            fprintf(stderr, "antidiagonalSmithWaterman: %s\n", agx_last_error());
-            return EXIT_FAILURE;
+        if (!status) {
+            if (single) rc = agx_sw_score(warm.ctx, t->bases, t->off, t->len, t->n_pairs, scores);
+            else if (n_dev) rc = agx_sw_score_devices(devices, n_dev, t->bases, t->off, t->len, t->n_pairs, scores);
+            else rc = agx_sw_score_multi(n_multi, t->bases, t->off, t->len, t->n_pairs, scores);
+            if (rc != AGX_OK) {
+                fprintf(stderr, "antidiagonalSmithWaterman: %s\n", agx_last_error());
+                status = EXIT_FAILURE;
+            }
         }
         t_score += seconds() - ta;
-        ta = seconds();
-        for (int64_t p = 0; p < t->n_pairs; p++) printf("Score: %d\n", scores[p]); /* :348 */
-        if (t->dangling) printf("%s", t->dangling);                                /* :225 */
-        t_print += seconds() - ta;
-        free(scores);
-        agx_sw_text_free(t);
+        if (status) { /* drain the parser so it can finish, print nothing more */
+            free(scores);
+            free(c);
+            agx_sw_text_free(t);
+            while ((t = (agx_sw_text *)agx_pipe_pop(&ps.q)) != NULL) agx_sw_text_free(t);
+            break;
+        }
+        c->text = t;
+        c->scores = scores;
+        agx_pipe_push(&pr.q, c);
         n_chunks++;
     }
     pthread_join(parser, NULL);
-    if (q.rc != AGX_OK) {
-        fprintf(stderr, "antidiagonalSmithWaterman: %s\n", q.err);
+    agx_pipe_close(&pr.q);
+    pthread_join(printer, NULL);
+    if (status) return status;
+    if (ps.rc != AGX_OK) {
+        fprintf(stderr, "antidiagonalSmithWaterman: %s\n", ps.err);
         return EXIT_FAILURE;
     }
     if (!warm_joined) pthread_join(warmer, NULL); /* no pair in the file: nothing needed the device */
     printf("elapsed %f\n", seconds() - t0); /* :351-352 */
     if (trace)
-        fprintf(stderr, "[cli] %lld chunk(s): waited for the parser %.3f s, score %.3f s, print %.3f s, total %.3f s\n",
-                (long long)n_chunks, t_wait, t_score, t_print, seconds() - tr0);
+        fprintf(stderr, "[cli] %lld chunk(s): waited for the parser %.3f s, score %.3f s, printer busy %.3f s, total %.3f s\n",
+                (long long)n_chunks, t_wait, t_score, pr.t_print, seconds() - tr0);
     if (warm.ctx) agx_ctx_destroy(warm.ctx);
-    agx_sw_reader_close(q.reader);
+    agx_sw_reader_close(ps.reader);
     return 0;
 }

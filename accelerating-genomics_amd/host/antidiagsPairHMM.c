@@ -9,13 +9,84 @@
  * program pairHMM/pairHMMmatrix.c has the same command line and output file but prints only the
  * `#batch:` lines on stdout (:171 vs its fprintf at :258).
  *   AGX_PHMM_PRECISION = f64 (default; raw sums bit-identical to the reference) | f64fma | f32 | f32fma
- *   AGX_NUM_DEVICES    = n GPUs to shard whole batches over (default 1, 0 = all)
+ *   AGX_NUM_DEVICES = n   shard whole batches over GPUs 0..n-1 (default 1, 0 = all visible)
+ *   AGX_DEVICES = 0,0,1   explicit list, one shard per entry (an ordinal may repeat)
+ *   AGX_CLI_CHUNK_PAIRS   pairs per pipeline step, whole batches (default 65536)
+ *
+ * Streaming, the reference's batch loop (:371-433, :484-489) as a pipeline of three
+ * threads: the parser reads batches k+1.. while the main thread has batch k on the device and the
+ * printer formats and writes batch k-1.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "agx.h"
+#include "agx_pipe.h"
+
+typedef struct {
+    agx_phmm_reader *reader;
+    int64_t chunk_pairs;
+    agx_pipe q;
+    int rc;
+    char err[512];
+} parse_stage;
+
+static void *parser_main(void *arg)
+{
+    parse_stage *s = (parse_stage *)arg;
+    while (!agx_phmm_reader_done(s->reader)) {
+        agx_phmm_text *t = NULL;
+        const int rc = agx_phmm_reader_next(s->reader, s->chunk_pairs, &t);
+        if (rc != AGX_OK) {
+            s->rc = rc;
+            snprintf(s->err, sizeof s->err, "%s", agx_last_error());
+            break;
+        }
+        agx_pipe_push(&s->q, t);
+    }
+    agx_pipe_close(&s->q);
+    return NULL;
+}
+
+typedef struct {
+    agx_phmm_text *text;
+    double *lh;
+} scored_chunk;
+
+typedef struct {
+    agx_pipe q;
+    FILE *out;
+    uint32_t batches; /* `#batch:` lines printed so far */
+} print_stage;
+
+static void *printer_main(void *arg)
+{
+    print_stage *s = (print_stage *)arg;
+    for (;;) {
+        scored_chunk *c = (scored_chunk *)agx_pipe_pop(&s->q);
+        if (!c) break;
+        const agx_phmm_desc *d = &c->text->desc;
+        int64_t k = 0;
+        char line[64];
+        for (uint32_t g = 0; g < d->n_regions; g++) {
+            printf("#batch: %u\n", ++s->batches); /* :372 */
+            const int64_t n = (int64_t)(d->region_read[g + 1] - d->region_read[g]) * (d->region_hap[g + 1] - d->region_hap[g]);
+            for (int64_t i = 0; i < n; i++, k++) {
+                const int len = snprintf(line, sizeof line, "%f\n", c->lh[k]); /* formatted once, written twice */
+#ifndef AGX_PHMM_MATRIX_STDOUT
+                fwrite(line, 1, (size_t)len, stdout); /* :459 */
+#endif
+                fwrite(line, 1, (size_t)len, s->out); /* :461 */
+            }
+        }
+        free(c->lh);
+        agx_phmm_text_free(c->text);
+        free(c);
+    }
+    return NULL;
+}
 
 int main(int argc, const char *argv[])
 {
@@ -23,14 +94,17 @@ int main(int argc, const char *argv[])
         fprintf(stderr, "Usage: %s <input_file_r> <output_file>\n", argv[0]); /* :314-317 */
         return EXIT_FAILURE;
     }
-    agx_phmm_text *t = NULL;
-    int rc = agx_phmm_text_read(argv[1], &t);
+    parse_stage ps;
+    memset(&ps, 0, sizeof ps);
+    int rc = agx_phmm_reader_open(argv[1], &ps.reader);
     if (rc != AGX_OK) {
         fprintf(stderr, "%s\n", agx_last_error()); /* perror("Error opening input file_r"), :320-324 */
         return EXIT_FAILURE;
     }
-    FILE *out = fopen(argv[2], "w");
-    if (!out) {
+    print_stage pr;
+    memset(&pr, 0, sizeof pr);
+    pr.out = fopen(argv[2], "w");
+    if (!pr.out) {
         perror("Error opening output file"); /* :333-339 */
         return EXIT_FAILURE;
     }
@@ -39,39 +113,64 @@ int main(int argc, const char *argv[])
     if (pe && strcmp(pe, "f32") == 0) precision = AGX_PHMM_F32;
     else if (pe && strcmp(pe, "f32fma") == 0) precision = AGX_PHMM_F32_FMA;
     else if (pe && strcmp(pe, "f64fma") == 0) precision = AGX_PHMM_F64_FMA;
+    int devices[64];
+    const int n_dev = agx_parse_devices(getenv("AGX_DEVICES"), devices, 64);
     const char *nd = getenv("AGX_NUM_DEVICES");
-    int n_dev = nd ? atoi(nd) : 1;
-
-    double *lh = (double *)malloc(sizeof(double) * (size_t)(t->n_pairs ? t->n_pairs : 1));
-    if (!lh) {
-        fprintf(stderr, "Error allocating memory for matrices.\n");
+    const int n_multi = nd ? atoi(nd) : 1;
+    const char *cp = getenv("AGX_CLI_CHUNK_PAIRS");
+    ps.chunk_pairs = cp && atoll(cp) > 0 ? atoll(cp) : 65536;
+    agx_pipe_init(&ps.q, 2);
+    agx_pipe_init(&pr.q, 2);
+    pthread_t parser, printer;
+    if (pthread_create(&parser, NULL, parser_main, &ps) || pthread_create(&printer, NULL, printer_main, &pr)) {
+        fprintf(stderr, "antidiagsPairHMM: cannot start threads\n");
         return EXIT_FAILURE;
     }
-    rc = agx_phmm_forward_multi(n_dev, &t->desc, precision, lh);
-    if (rc != AGX_OK) {
-        fprintf(stderr, "antidiagsPairHMM: %s\n", agx_last_error());
-        return EXIT_FAILURE;
-    }
-    int64_t k = 0;
-    const agx_phmm_desc *d = &t->desc;
-    for (uint32_t g = 0; g < d->n_regions; g++) {
-        printf("#batch: %u\n", g + 1); /* :372 */
-        int64_t n = (int64_t)(d->region_read[g + 1] - d->region_read[g]) * (d->region_hap[g + 1] - d->region_hap[g]);
-        for (int64_t i = 0; i < n; i++, k++) {
-#ifndef AGX_PHMM_MATRIX_STDOUT
-            printf("%f\n", lh[k]);       /* :459 */
-#endif
-            fprintf(out, "%f\n", lh[k]); /* :461 */
+    int status = EXIT_SUCCESS, truncated = 0;
+    for (;;) {
+        agx_phmm_text *t = (agx_phmm_text *)agx_pipe_pop(&ps.q);
+        if (!t) break;
+        truncated |= t->truncated;
+        scored_chunk *c = (scored_chunk *)calloc(1, sizeof *c);
+        double *lh = (double *)malloc(sizeof(double) * (size_t)(t->n_pairs ? t->n_pairs : 1));
+        if (!c || !lh) {
+            fprintf(stderr, "Error allocating memory for matrices.\n");
+            status = EXIT_FAILURE;
         }
+        if (status == EXIT_SUCCESS && t->n_pairs) {
+            rc = n_dev ? agx_phmm_forward_devices(devices, n_dev, &t->desc, precision, lh)
+                       : agx_phmm_forward_multi(n_multi, &t->desc, precision, lh);
+            if (rc != AGX_OK) {
+                fprintf(stderr, "antidiagsPairHMM: %s\n", agx_last_error());
+                status = EXIT_FAILURE;
+            }
+        }
+        if (status != EXIT_SUCCESS) { /* drain the parser so it can finish, print nothing more */
+            free(lh);
+            free(c);
+            agx_phmm_text_free(t);
+            while ((t = (agx_phmm_text *)agx_pipe_pop(&ps.q)) != NULL) agx_phmm_text_free(t);
+            break;
+        }
+        c->text = t;
+        c->lh = lh;
+        agx_pipe_push(&pr.q, c);
     }
-    printf("#batch: %u\n", d->n_regions + 1); /* the turn that meets EOF, or the truncated batch */
-    int status = EXIT_SUCCESS;
-    if (t->truncated) {
-        fprintf(stderr, "Error reading haplotypes.\n"); /* :394-398 */
+    pthread_join(parser, NULL);
+    agx_pipe_close(&pr.q);
+    pthread_join(printer, NULL);
+    if (status == EXIT_SUCCESS && ps.rc != AGX_OK) {
+        fprintf(stderr, "antidiagsPairHMM: %s\n", ps.err);
         status = EXIT_FAILURE;
     }
-    fclose(out);
-    free(lh);
-    agx_phmm_text_free(t);
+    if (status == EXIT_SUCCESS) {
+        printf("#batch: %u\n", pr.batches + 1); /* the turn that meets EOF, or the truncated batch */
+        if (truncated) {
+            fprintf(stderr, "Error reading haplotypes.\n"); /* :394-398 */
+            status = EXIT_FAILURE;
+        }
+    }
+    fclose(pr.out);
+    agx_phmm_reader_close(ps.reader);
     return status;
 }

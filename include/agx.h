@@ -65,6 +65,8 @@ int agx_device_count(void);       /* >= 0; 0 when HIP reports no device */
 int agx_device_name(int device, char *buf, size_t buf_len);
 
 int agx_ctx_create(int device, agx_ctx **out);
+/* Batches keep their context alive: a context may be destroyed before the batches created from it
+ * (its streams and memory pools go with the last of them). */
 void agx_ctx_destroy(agx_ctx *ctx);
 int agx_ctx_device(const agx_ctx *ctx);
 /* The hipStream_t all launches of this context go to (as void*).  A host that
@@ -72,6 +74,18 @@ int agx_ctx_device(const agx_ctx *ctx);
 void *agx_ctx_stream(const agx_ctx *ctx);
 int agx_ctx_set_stream(agx_ctx *ctx, void *hip_stream);
 int agx_ctx_sync(agx_ctx *ctx);
+/* Options.  The library reads no environment variable; whatever a host wants changed it sets here. */
+#define AGX_OPT_SW_KERNEL 1 /* which Smith-Waterman fill runs; all give identical scores */
+#define AGX_SW_KERNEL_AUTO 0          /* packed int16 x 2 when the batch's value range allows, else int32 */
+#define AGX_SW_KERNEL_INT32 1         /* one pair per lane group, int32 state (BASELINE config 2 as worded) */
+#define AGX_SW_KERNEL_PACKED_SIGNED 2 /* two pairs per lane group, signed int16 halves */
+#define AGX_SW_KERNEL_PACKED_BIASED 3 /* two pairs per lane group, biased unsigned halves (the default where it fits) */
+int agx_ctx_set_option(agx_ctx *ctx, int key, int64_t value);
+/* Page-locked host memory.  Batches built from buffers allocated here are uploaded by DMA straight from
+ * the caller's memory (about twice the rate of pageable memory, and asynchronously).  Optional: every
+ * entry point accepts ordinary malloc'ed buffers. */
+void *agx_host_alloc(size_t bytes); /* NULL on failure */
+void agx_host_free(void *p);
 /* HIP-event stopwatch on the context's stream (used by bench.py for the roofline figures). */
 int agx_ctx_timer_start(agx_ctx *ctx);
 int agx_ctx_timer_stop(agx_ctx *ctx, float *elapsed_ms);
@@ -145,9 +159,17 @@ void agx_sw_batch_destroy(agx_sw_batch *b);
 int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
                  int32_t *scores);
 /* Same, sharded by cells over `n_devices` devices (<= 0: all visible), one host
- * thread and context per device, no collective. */
+ * thread and context per device, no collective.  The per-device contexts and
+ * their memory pools are created on first use and kept for later calls. */
 int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
                        int64_t n_pairs, int32_t *scores);
+/* Same with an explicit device list: shard k runs on devices[k].  An ordinal may appear several times
+ * (several shards then share that GPU, each with its own context and stream). */
+int agx_sw_score_devices(const int *devices, int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
+                         int64_t n_pairs, int32_t *scores);
+/* The cut rule of the two calls above, on the host alone: cut[0..n_shards] with shard k = pairs
+ * [cut[k], cut[k+1]), contiguous and balanced by sum(len_a * len_b + 1). */
+int agx_sw_shard_cuts(const uint32_t *len, int64_t n_pairs, int n_shards, int64_t *cut);
 
 /* ------------------------------------------------------------------ PairHMM */
 
@@ -212,6 +234,11 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b);
 
 int agx_phmm_forward(agx_ctx *ctx, const agx_phmm_desc *d, int precision, double *log10_lik);
 int agx_phmm_forward_multi(int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik);
+/* Explicit device list, as agx_sw_score_devices. */
+int agx_phmm_forward_devices(const int *devices, int n_devices, const agx_phmm_desc *d, int precision, double *log10_lik);
+/* The cut rule: cut[0..n_shards] in REGIONS (whole regions stay together), balanced by
+ * (read bytes x haplotype bytes + 1) per region. */
+int agx_phmm_shard_cuts(const agx_phmm_desc *d, int n_shards, uint32_t *cut);
 
 /*
  * The reference's only function-level seam, same argument list as
@@ -267,6 +294,18 @@ typedef struct agx_phmm_text {
 
 int agx_phmm_text_read(const char *path, agx_phmm_text **out);
 void agx_phmm_text_free(agx_phmm_text *t);
+
+/* The same reader in pieces of whole regions -- the reference's batch loop, antidiagsPairHMM.c:371-433,484-489 --
+ * so a host can have region k+1 parsed while region k is on the device and region k-1 is printed
+ * (host/antidiagsPairHMM.c does).  Every next() returns a fresh agx_phmm_text, which the caller frees, holding the
+ * regions up to the first one that brings it to max_pairs pairs (at least one region; indices and offsets
+ * relative to the chunk); n_regions_seen counts the header lines read for it and `truncated` marks the chunk
+ * that met a region cut short (the reader is done then, as the reference exits there). */
+typedef struct agx_phmm_reader agx_phmm_reader;
+int agx_phmm_reader_open(const char *path, agx_phmm_reader **out);
+int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **out);
+int agx_phmm_reader_done(const agx_phmm_reader *r);
+void agx_phmm_reader_close(agx_phmm_reader *r);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@
  * file; the product (libagx.so, the drop-in CLIs) never links or loads it.
  *
  * Parity status: PINNED.  tests/test_oracle_sw.py checks both functions below
- * against tests/golden/sw_*.scores, which were produced in the authoring
+ * against tests/golden/sw_*.expect, which were produced in the authoring
  * container by oracle/_ref/sw_ref = `gcc -O3` of the unmodified reference
  * source (recipe: oracle/Makefile, generator: tests/golden/make_golden.py).
  * The reference repo itself holds no SW fixture.

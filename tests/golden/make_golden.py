@@ -8,6 +8,7 @@ byte for byte.  Expected outputs are what the unmodified reference programs
 print, run here through oracle/_ref (recipe: oracle/Makefile `make ref`):
 
   sw_*.in        -> sw_*.expect      stdout of sw_ref minus its `elapsed` line
+                                     (sw_config1.in is BASELINE config 1 itself: `2\n<a>\n<b>\n`, seed 1)
   phmm_*.in      -> phmm_*.f.out     output file of phmm_matrix_ref      ("%f")
                     phmm_*.g17.out   output file of phmm_matrix_ref_g17  ("%.17g")
 
@@ -77,8 +78,10 @@ def main():
     synth.write_sw_file(os.path.join(HERE, "sw_hdr_big.in"), b, header=100)    # EOF ends the loop
     lines = [b.seq(k) for k in range(11)]                                      # odd number of lines: last one unpaired
     w("sw_oddlines.in", b"12\n" + b"".join(lines))
+    # BASELINE config 1 literally: one pair of iid 150-mers, seed 1, file `2\n<a>\n<b>\n`
+    synth.write_sw_file(os.path.join(HERE, "sw_config1.in"), synth.sw_pairs(1, 150, 150, seed=1))
     for n in ("sw_kat", "sw_nofinalnl", "sw_150", "sw_mixed", "sw_long", "sw_short", "sw_hdr_half", "sw_hdr_odd",
-              "sw_hdr_big", "sw_oddlines"):
+              "sw_hdr_big", "sw_oddlines", "sw_config1"):
         run_sw(n)
     # ---------------------------------------------------------------- PairHMM
     for src, dst in (("test.in", "phmm_test.in"), ("test.out", "phmm_test.out"), ("10s.in", "phmm_10s.in")):

@@ -148,3 +148,55 @@ def test_block_reader_has_fgets_semantics_and_chunks_concatenate(tmp_path, seed,
                 got += [cb.seq(k) for k in range(2 * cb.n_pairs)]
                 dangs.append(d)
             assert got == want and [d for d in dangs if d is not None] == ([dangling] if dangling is not None else [])
+
+
+@pytest.mark.parametrize("name", ["phmm_10s", "phmm_synth", "phmm_long"])
+@pytest.mark.parametrize("max_pairs", [1, 100, 10 ** 9])
+def test_phmm_reader_hands_out_whole_regions(golden_dir, name, max_pairs):
+    """agx_phmm_reader_*: the reference's batch loop (antidiagsPairHMM.c:371-433,484-489) in pieces.  Chunks are whole
+    regions, at least one per call, cut at the first region that reaches max_pairs; together they are the file."""
+    path = os.path.join(golden_dir, name + ".in")
+    whole, seen, trunc = agx.read_phmm_text(path)
+    chunks = list(agx.read_phmm_text_chunks(path, max_pairs))
+    assert sum(c[1] for c in chunks) == seen and not any(c[2] for c in chunks) and trunc == 0
+    assert sum(c[0].n_regions for c in chunks) == whole.n_regions and sum(c[0].n_pairs for c in chunks) == whole.n_pairs
+    for c, _, _ in chunks[:-1]:
+        assert c.n_regions >= 1
+        if max_pairs < 10 ** 9:
+            before_last = c.n_pairs - int((c.rreg[-1] - c.rreg[-2]) * (c.hreg[-1] - c.hreg[-2]))
+            assert before_last < max_pairs <= c.n_pairs or c.n_regions == 1
+    for f in ("read_bases", "q_base", "q_ins", "q_del", "q_gcp", "hap_bases"):
+        assert np.array_equal(np.concatenate([getattr(c[0], f) for c in chunks]), getattr(whole, f)), f
+    assert np.array_equal(np.concatenate([np.diff(c[0].roff) for c in chunks]), np.diff(whole.roff))
+    assert np.array_equal(np.concatenate([np.diff(c[0].hoff) for c in chunks]), np.diff(whole.hoff))
+
+
+def test_phmm_reader_truncated_region_ends_the_stream(tmp_path, golden_dir):
+    data = open(os.path.join(golden_dir, "phmm_synth.in"), "rb").read().split(b"\n")
+    (tmp_path / "cut.in").write_bytes(b"\n".join(data[:14]) + b"\n")  # region 1 complete, region 2 cut short
+    chunks = list(agx.read_phmm_text_chunks(str(tmp_path / "cut.in"), 1))
+    assert [(c[0].n_regions, c[1], c[2]) for c in chunks] == [(1, 1, 0), (0, 1, 1)]
+
+
+def test_shard_cut_rules_match_the_python_mirror():
+    """agx_sw_shard_cuts / agx_phmm_shard_cuts (what agx_*_devices and bench.py's strong-scaling leg cut by) against
+    dist.shard_bounds, the rule bench.py's ranks use: contiguous, balanced by cells, every unit in exactly one shard."""
+    import accelerating_genomics_amd.dist as agd
+
+    for seed, n in ((1, 1), (2, 7), (3, 1000), (4, 20000)):
+        b = synth.sw_pairs(n, 1, 400, seed=seed)
+        cost = b.len[0::2].astype(np.float64) * b.len[1::2].astype(np.float64)
+        for shards in (1, 2, 3, 8, 64):
+            cut = agx.sw_shard_cuts(b, shards)
+            assert np.array_equal(cut, agd.shard_bounds(cost, shards)), (n, shards)
+            assert cut[0] == 0 and cut[-1] == n and np.all(np.diff(cut) >= 0)
+            if n >= 1000 and shards <= 8:
+                per = np.add.reduceat(cost, cut[:-1])
+                assert per.max() / per.mean() < 1.05
+    p = synth.phmm_regions(37, 5, 3, 80, 160, seed=5, jitter=40)
+    rb = np.diff(p.roff[p.rreg].astype(np.float64))
+    hb = np.diff(p.hoff[p.hreg].astype(np.float64))
+    for shards in (1, 2, 5, 8, 50):
+        cut = agx.phmm_shard_cuts(p, shards)
+        assert np.array_equal(cut.astype(np.int64), agd.shard_bounds(rb * hb, shards))
+    assert list(agx.sw_shard_cuts(synth.sw_from_seqs([]), 4)) == [0, 0, 0, 0, 0]

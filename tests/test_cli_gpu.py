@@ -109,8 +109,8 @@ def test_pairhmmmatrix_alias(golden_dir, tmp_path):
 
 
 def test_clis_shard_over_several_devices(golden_dir, tmp_path):
-    """AGX_NUM_DEVICES > 1 (here oversubscribed onto this box's GPU): same bytes out."""
-    env = dict(os.environ, AGX_NUM_DEVICES="3", AGX_MULTI_OVERSUBSCRIBE="1", AGX_CLI_CHUNK_PAIRS="100")
+    """AGX_DEVICES names one GPU per shard (here this box's GPU three times): same bytes out."""
+    env = dict(os.environ, AGX_DEVICES="0,0,0", AGX_CLI_CHUNK_PAIRS="100")
     r = subprocess.run([os.path.join(BIN, "antidiagonalSmithWaterman"), os.path.join(golden_dir, "sw_mixed.in")],
                        capture_output=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
@@ -121,3 +121,44 @@ def test_clis_shard_over_several_devices(golden_dir, tmp_path):
                        capture_output=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert outp.read_bytes() == open(os.path.join(golden_dir, "phmm_10s.f.out"), "rb").read()
+
+
+@pytest.mark.parametrize("name", ["phmm_test", "phmm_10s", "phmm_synth", "phmm_far", "phmm_long"])
+@pytest.mark.parametrize("chunk", ["1", "200"])
+def test_phmm_cli_streams_by_whole_batches(golden_dir, tmp_path, name, chunk):
+    """the batch loop of antidiagsPairHMM.c:371-433,484-489 as a pipeline (parse k+1 | device k |
+    print k-1).  With a chunk of 1 pair every batch is its own pipeline step: same file, same stdout."""
+    outp = tmp_path / "o.out"
+    r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), os.path.join(golden_dir, name + ".in"), str(outp)],
+                       capture_output=True, timeout=300, env=dict(os.environ, AGX_CLI_CHUNK_PAIRS=chunk))
+    assert r.returncode == 0, r.stderr
+    want = open(os.path.join(golden_dir, name + ".f.out"), "rb").read()
+    assert outp.read_bytes() == want
+    whole = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), os.path.join(golden_dir, name + ".in"), str(tmp_path / "w.out")],
+                           capture_output=True, timeout=300, env=dict(os.environ, AGX_CLI_CHUNK_PAIRS="100000000"))
+    assert whole.returncode == 0 and r.stdout == whole.stdout  # the `#batch:` lines sit where they sat
+    lines = r.stdout.splitlines(keepends=True)
+    nb = [l for l in lines if l.startswith(b"#batch")]
+    assert nb == [b"#batch: %d\n" % (i + 1) for i in range(len(nb))] and lines[-1] == nb[-1]
+
+
+def test_phmm_cli_streaming_truncated_batch(golden_dir, tmp_path):
+    """A batch cut short in a later pipeline step: the complete batches are written, then the reference's failure."""
+    data = open(os.path.join(golden_dir, "phmm_synth.in"), "rb").read().split(b"\n")
+    (tmp_path / "cut.in").write_bytes(b"\n".join(data[:14]) + b"\n")
+    r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), str(tmp_path / "cut.in"), str(tmp_path / "cut.out")],
+                       capture_output=True, env=dict(os.environ, AGX_CLI_CHUNK_PAIRS="1"))
+    assert r.returncode == 1 and r.stderr == b"Error reading haplotypes.\n"
+    assert (tmp_path / "cut.out").read_bytes() == b"".join(open(os.path.join(golden_dir, "phmm_synth.f.out"), "rb").readlines()[:24])
+    assert [l for l in r.stdout.splitlines() if l.startswith(b"#batch")] == [b"#batch: 1", b"#batch: 2"]
+
+
+def test_sw_cli_config1_literal_fixture(golden_dir):
+    """BASELINE config 1 as SURVEY 8d words it: the file `2\\n<a>\\n<b>\\n`, two iid 150-mers (seed 1); expected stdout
+    from the compiled reference (tests/golden/make_golden.py)."""
+    out = subprocess.run([os.path.join(BIN, "antidiagonalSmithWaterman"), os.path.join(golden_dir, "sw_config1.in")],
+                         capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines(keepends=True)
+    assert lines[0] == b"line_num: 2\n" and len(lines) == 3
+    assert b"".join(lines[:-1]) == open(os.path.join(golden_dir, "sw_config1.expect"), "rb").read()

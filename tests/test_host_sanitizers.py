@@ -15,10 +15,10 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang"
 def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
     import accelerating_genomics_amd.api as agx
 
-    if not os.path.exists(os.path.join(PKG, "build", "agx_sw_pk_kernel.o")):
+    if not os.path.exists(os.path.join(PKG, "build", "agx_sw_pack_kernel.o")):
         agx.build()
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
-    inc = ["-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"]
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-DAGX_TUNING"]  # AGX_HOST_THREADS below
     objs = []
     for src in ("agx_runtime.cpp", "agx_sw.cpp", "agx_phmm.cpp"):
         o = str(tmp_path / (src + ".o"))
@@ -29,7 +29,7 @@ def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
         o = str(tmp_path / (os.path.basename(src) + ".o"))
         subprocess.run([CLANG, "-std=c99", *san, *inc, *extra, "-c", src, "-o", o], check=True)
         objs.append(o)
-    dev = [os.path.join(PKG, "build", n) for n in ("agx_sw_kernel.o", "agx_sw_wide_kernel.o", "agx_sw_pk_kernel.o", "agx_sw_mat_kernel.o", "agx_phmm_kernel.o", "agx_phmm_pk_kernel.o", "agx_phmm_stripe_kernel.o")]
+    dev = [os.path.join(PKG, "build", n) for n in ("agx_sw_kernel.o", "agx_sw_wide_kernel.o", "agx_sw_pk_kernel.o", "agx_sw_pk2_kernel.o", "agx_sw_pack_kernel.o", "agx_sw_mat_kernel.o", "agx_phmm_kernel.o", "agx_phmm_pk_kernel.o", "agx_phmm_stripe_kernel.o")]
     exe = str(tmp_path / "sanitize_driver")
     subprocess.run([CLANG + "++", *san, *objs, *dev, "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)

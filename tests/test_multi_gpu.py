@@ -1,8 +1,8 @@
-"""agx_sw_score_multi / agx_phmm_forward_multi (one host thread and context per device,
-contiguous shards balanced by cells, no collective) with more shards than this box has GPUs:
-AGX_MULTI_OVERSUBSCRIBE maps shard k to device k % visible, so the sharding and the aggregation into
-the caller's arrays run here as they would on an 8-GPU node.  Subprocess: the knob is read per call,
-but a clean environment keeps the other tests' contexts out of the picture."""
+"""agx_sw_score_devices / agx_phmm_forward_devices (one host thread and context per shard,
+contiguous shards balanced by cells, no collective) with more shards than this box has GPUs: the
+device list names GPU 0 several times, so the sharding and the aggregation into the caller's arrays run
+here as they would on an 8-GPU node (agx_*_multi(n) is the same call with devices 0..n-1).  Subprocess:
+a clean process keeps the other tests' contexts out of the picture."""
 import os
 import subprocess
 import sys
@@ -21,23 +21,32 @@ from tests import oracle_api
 orc = oracle_api.load()
 for n_dev in (2, 3, 8):
     b = synth.sw_pairs(3001, 1, 300, seed=40 + n_dev, related_frac=0.4)
-    assert np.array_equal(agx.sw_score_multi(b, n_dev), orc.sw_batch(b)), ("sw", n_dev)
+    assert np.array_equal(agx.sw_score_devices(b, [0] * n_dev), orc.sw_batch(b)), ("sw", n_dev)
     p = synth.phmm_regions(11, 5, 3, 60, 120, seed=50 + n_dev, jitter=30)
     s_ref, l_ref = orc.phmm_batch(p, 0)
-    assert np.array_equal(agx.phmm_forward_multi(p, agx.PHMM_F64, n_dev), l_ref), ("phmm", n_dev)
-    got = agx.phmm_forward_multi(p, agx.PHMM_F32_FMA, n_dev)
+    assert np.array_equal(agx.phmm_forward_devices(p, [0] * n_dev, agx.PHMM_F64), l_ref), ("phmm", n_dev)
+    got = agx.phmm_forward_devices(p, [0] * n_dev, agx.PHMM_F32_FMA)
     assert np.max(np.abs(got - l_ref) / np.abs(l_ref)) <= 1e-6
 # more shards than pairs / regions, and empty input
 b = synth.sw_pairs(3, 5, 9, seed=1)
-assert np.array_equal(agx.sw_score_multi(b, 8), orc.sw_batch(b))
+assert np.array_equal(agx.sw_score_devices(b, [0] * 8), orc.sw_batch(b))
 p = synth.phmm_regions(2, 2, 2, 10, 20, seed=2)
-assert np.array_equal(agx.phmm_forward_multi(p, agx.PHMM_F64, 8), orc.phmm_batch(p, 0)[1])
-assert agx.sw_score_multi(synth.sw_from_seqs([]), 4).size == 0
+assert np.array_equal(agx.phmm_forward_devices(p, [0] * 8, agx.PHMM_F64), orc.phmm_batch(p, 0)[1])
+assert agx.sw_score_devices(synth.sw_from_seqs([]), [0] * 4).size == 0
+# the same calls a second time: the per-shard contexts and their pools are reused
+b = synth.sw_pairs(2000, 20, 200, seed=77)
+for _ in range(3):
+    assert np.array_equal(agx.sw_score_devices(b, [0, 0]), orc.sw_batch(b))
+assert np.array_equal(agx.sw_score_multi(b, 0), orc.sw_batch(b))  # all visible devices
+try:
+    agx.sw_score_devices(b, [0, 99])
+    raise SystemExit("a device ordinal out of range was accepted")
+except agx.AgxError as e:
+    assert e.code == agx.E_NODEVICE
 print("MULTI_OK")
 ''' % ROOT
 
 
 def test_multi_device_sharding_with_oversubscription():
-    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, AGX_MULTI_OVERSUBSCRIBE="1"))
+    r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MULTI_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
