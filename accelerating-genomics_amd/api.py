@@ -27,7 +27,7 @@ PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
 SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
     "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_set_option", "agx_host_alloc", "agx_host_free",
-    "agx_ctx_timer_start", "agx_ctx_timer_stop",
+    "agx_ctx_timer_start", "agx_ctx_timer_stop", "agx_ctx_timer_mark", "agx_ctx_timer_elapsed",
     "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi", "agx_sw_score_devices", "agx_sw_shard_cuts",
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
@@ -128,6 +128,8 @@ def lib():
         l.agx_host_free.restype = None
         l.agx_ctx_timer_start.argtypes = [C.c_void_p]
         l.agx_ctx_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.agx_ctx_timer_mark.argtypes = [C.c_void_p]
+        l.agx_ctx_timer_elapsed.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.agx_sw_batch_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.POINTER(C.c_void_p)]
         l.agx_sw_batch_create_scored.argtypes = [C.c_void_p, C.POINTER(SwScoring), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -232,6 +234,14 @@ class Context:
         _check(lib().agx_ctx_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    def timer_mark(self):
+        _check(lib().agx_ctx_timer_mark(self._h))
+
+    def timer_elapsed(self) -> float:
+        ms = C.c_float()
+        _check(lib().agx_ctx_timer_elapsed(self._h, C.byref(ms)))
+        return ms.value
+
     # ---- Smith-Waterman
     def sw_batch(self, b, scoring=None, matrix=None) -> "SwBatch":
         return SwBatch(self, b, scoring, matrix)
@@ -273,8 +283,9 @@ class SwBatch:
     def launch(self):
         _check(lib().agx_sw_batch_launch(self._h))
 
-    def scores(self) -> np.ndarray:
-        out = np.empty(self.n_pairs, np.int32)
+    def scores(self, out=None) -> np.ndarray:
+        if out is None:
+            out = np.empty(self.n_pairs, np.int32)
         _check(lib().agx_sw_batch_scores(self._h, _ptr(out)))
         return out
 
@@ -319,10 +330,9 @@ class PhmmBatchDev:
     def launch(self):
         _check(lib().agx_phmm_batch_launch(self._h))
 
-    def results(self):
-        """-> (log10 likelihoods, raw sums), float64."""
-        l = np.empty(self.n_pairs, np.float64)
-        s = np.empty(self.n_pairs, np.float64)
+    def results(self, out=None):
+        """-> (log10 likelihoods, raw sums), float64; out = (l, s) arrays to reuse."""
+        l, s = out if out is not None else (np.empty(self.n_pairs, np.float64), np.empty(self.n_pairs, np.float64))
         _check(lib().agx_phmm_batch_results(self._h, _ptr(l), _ptr(s)))
         return l, s
 

@@ -237,46 +237,70 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    // ---- enumerate the pairs in output order: region, read, haplotype
+    // ---- enumerate the pairs in output order: region, read, haplotype (threads over regions)
     std::vector<Plan> gen0;
     int64_t n_pairs = 0, cells = 0;
-    for (uint32_t g = 0; g < d->n_regions; ++g) {
-        const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
-        const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
-        if (r1 < r0 || h1 < h0 || r1 > d->n_reads || h1 > d->n_haps) {
-            agx_set_error("region %u: read/haplotype ranges out of order or out of bounds", g);
-            return AGX_E_ARG;
-        }
-        for (uint32_t r = r0; r < r1; ++r) {
-            const uint64_t R = d->read_off[r + 1] - d->read_off[r];
-            for (uint32_t h = h0; h < h1; ++h) {
-                const uint64_t H = d->hap_off[h + 1] - d->hap_off[h];
-                if (R > AGX_PHMM_MAX_READ_LEN || H > AGX_PHMM_MAX_HAP_LEN) {
-                    agx_set_error("pair (read %u, hap %u): %llu x %llu exceeds the supported %d x %d", r, h,
-                                  (unsigned long long)R, (unsigned long long)H, AGX_PHMM_MAX_READ_LEN, AGX_PHMM_MAX_HAP_LEN);
-                    return AGX_E_LIMIT;
-                }
-                Plan p{};
-                p.out = (uint32_t)n_pairs++;
-                cells += (int64_t)(R * H);
-                if (R == 0 || H == 0) continue; // sum over an empty row/all-zero row is 0 (log10 -> -inf)
-                p.read = r;
-                p.hap = h;
-                p.R = (uint32_t)R;
-                p.H = (uint32_t)H;
-                gen0.push_back(p);
+    {
+        const uint32_t ng = d->n_regions;
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
+            const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+            if (r1 < r0 || h1 < h0 || r1 > d->n_reads || h1 > d->n_haps) {
+                agx_set_error("region %u: read/haplotype ranges out of order or out of bounds", g);
+                return AGX_E_ARG;
             }
         }
-        if (n_pairs > 0x7ffffff0LL) {
-            agx_set_error("more than 2^31 pairs in one batch");
-            return AGX_E_LIMIT;
+        // lengths are checked once per read / haplotype, not once per pair
+        for (uint32_t r = 0; d->read_off && r < d->n_reads; ++r)
+            if (d->read_off[r + 1] - d->read_off[r] > AGX_PHMM_MAX_READ_LEN) {
+                agx_set_error("read %u: %llu bases exceed the supported %d", r, (unsigned long long)(d->read_off[r + 1] - d->read_off[r]),
+                              AGX_PHMM_MAX_READ_LEN);
+                return AGX_E_LIMIT;
+            }
+        for (uint32_t h = 0; d->hap_off && h < d->n_haps; ++h)
+            if (d->hap_off[h + 1] - d->hap_off[h] > AGX_PHMM_MAX_HAP_LEN) {
+                agx_set_error("haplotype %u: %llu bases exceed the supported %d", h, (unsigned long long)(d->hap_off[h + 1] - d->hap_off[h]),
+                              AGX_PHMM_MAX_HAP_LEN);
+                return AGX_E_LIMIT;
+            }
+        // per region: output offset (every pair has an output slot) and offset into gen0 (pairs with work)
+        std::vector<int64_t> out0((size_t)ng + 1, 0), fill0((size_t)ng + 1, 0);
+        for (uint32_t g = 0; g < ng; ++g) {
+            const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+            int64_t nr = 0, nh = 0;
+            for (uint32_t r = r0; r < r1; ++r) nr += d->read_off[r + 1] != d->read_off[r];
+            for (uint32_t h = h0; h < h1; ++h) nh += d->hap_off[h + 1] != d->hap_off[h];
+            out0[g + 1] = out0[g] + (int64_t)(r1 - r0) * (h1 - h0);
+            fill0[g + 1] = fill0[g] + nr * nh;
+            cells += (int64_t)(d->read_off[r1] - d->read_off[r0]) * (int64_t)(d->hap_off[h1] - d->hap_off[h0]);
+            if (out0[g + 1] > 0x7ffffff0LL) {
+                agx_set_error("more than 2^31 pairs in one batch");
+                return AGX_E_LIMIT;
+            }
         }
-    }
-    if (!gen0.empty()) {
-        if (!d->read_bases || !d->hap_bases || (!probs && (!d->q_base || !d->q_ins || !d->q_del || !d->q_gcp))) {
-            agx_set_error("agx_phmm_batch_create: NULL track");
-            return AGX_E_ARG;
-        }
+        n_pairs = out0[ng];
+        gen0.resize((size_t)fill0[ng]);
+        agx_parallel_for((int64_t)ng, 1, [&](int64_t ga, int64_t gz, int) {
+            for (int64_t g = ga; g < gz; ++g) {
+                const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+                size_t at = (size_t)fill0[(size_t)g];
+                int64_t o = out0[(size_t)g];
+                for (uint32_t r = r0; r < r1; ++r) {
+                    const uint32_t R = (uint32_t)(d->read_off[r + 1] - d->read_off[r]);
+                    for (uint32_t h = h0; h < h1; ++h, ++o) {
+                        const uint32_t H = (uint32_t)(d->hap_off[h + 1] - d->hap_off[h]);
+                        if (R == 0 || H == 0) continue; // sum over an empty row/all-zero row is 0 (log10 -> -inf)
+                        Plan p{};
+                        p.out = (uint32_t)o;
+                        p.read = r;
+                        p.hap = h;
+                        p.R = R;
+                        p.H = H;
+                        gen0[at++] = p;
+                    }
+                }
+            }
+        });
     }
 
     // ---- haplotypes wider than 64 lanes x the widest class of this arithmetic go to the striped kernel
@@ -296,41 +320,87 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         gen0.resize(keep);
     }
 
-    // ---- image: every read and haplotype once, shared by all plans of the batch
-    std::vector<uint32_t> img;
-    img.resize((64 * 32 + 8) / 4, 0u); // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 32 columns)
-    std::vector<uint32_t> read_dw(d->n_reads, 0xffffffffu), hap_dw(d->n_haps, 0xffffffffu);
-    auto put_read = [&](uint32_t r) {
-        if (read_dw[r] != 0xffffffffu) return;
-        const uint64_t o = d->read_off[r];
-        const uint32_t R = (uint32_t)(d->read_off[r + 1] - o);
-        const size_t trk = ((size_t)R + 3) / 4;
-        if (probs) {
-            if (img.size() & 1) img.push_back(0u); // doubles need 8-byte alignment
-            read_dw[r] = (uint32_t)img.size();
-            img.resize(img.size() + (size_t)R * 8 + trk, 0u);
-            double *q = reinterpret_cast<double *>(&img[read_dw[r]]);
-            for (int k = 0; k < 4; ++k) memcpy(q + (size_t)k * R, prob[k] + o, (size_t)R * sizeof(double));
-            memcpy(reinterpret_cast<uint8_t *>(q + (size_t)4 * R), d->read_bases + o, R);
-        } else {
-            read_dw[r] = (uint32_t)img.size();
-            img.resize(img.size() + 5 * trk, 0u);
-            uint8_t *p = reinterpret_cast<uint8_t *>(&img[read_dw[r]]);
-            const uint8_t *src[5] = {d->read_bases, d->q_base, d->q_ins, d->q_del, d->q_gcp};
-            for (int k = 0; k < 5; ++k) memcpy(p + (size_t)k * trk * 4, src[k] + o, R);
-        }
+    // ---- image: every read and haplotype once, shared by all plans of the batch.  Offsets come from two
+    // prefix sums, the bytes are copied by threads (the pairHMM() seam's probability tracks excepted: one pair);
+    // with a device the image is built straight in pinned staging memory.
+    const size_t zero_dw = (64 * 32 + 8) / 4; // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 32 columns)
+    const uint32_t n_reads = d->read_off ? d->n_reads : 0, n_haps = d->hap_off ? d->n_haps : 0;
+    std::vector<uint32_t> read_dw(n_reads, 0xffffffffu), hap_dw(n_haps, 0xffffffffu);
+    size_t img_dw = zero_dw;
+    const size_t stripe_bytes = 64u * (size_t)stripe_cols();
+    auto hap_block_dw = [&](size_t H) { // zero slack: any class tiling, and whole stripes of the striped kernel, read in bounds
+        const size_t bytes = std::max(H + kHapSlack, (H + stripe_bytes - 1) / stripe_bytes * stripe_bytes + 8);
+        return (bytes + 3) / 4;
     };
-    auto put_hap = [&](uint32_t h) {
-        if (hap_dw[h] != 0xffffffffu) return;
-        const uint64_t o = d->hap_off[h];
-        const uint32_t H = (uint32_t)(d->hap_off[h + 1] - o);
-        hap_dw[h] = (uint32_t)img.size();
-        // zero slack: any class tiling, and whole stripes of the striped kernel, read in bounds
-        const size_t stripe = 64u * (size_t)stripe_cols();
-        const size_t bytes = std::max((size_t)H + kHapSlack, ((size_t)H + stripe - 1) / stripe * stripe + 8);
-        img.resize(img.size() + (bytes + 3) / 4, 0u);
-        memcpy(reinterpret_cast<uint8_t *>(&img[hap_dw[h]]), d->hap_bases + o, H);
-    };
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const size_t R = (size_t)(d->read_off[r + 1] - d->read_off[r]), trk = (R + 3) / 4;
+        if (probs && (img_dw & 1)) ++img_dw; // doubles need 8-byte alignment
+        read_dw[r] = (uint32_t)img_dw;
+        img_dw += probs ? R * 8 + trk : 5 * trk;
+        if (img_dw > 0xfffffff0ull) break;
+    }
+    for (uint32_t h = 0; h < n_haps && img_dw <= 0xfffffff0ull; ++h) {
+        hap_dw[h] = (uint32_t)img_dw;
+        img_dw += hap_block_dw((size_t)(d->hap_off[h + 1] - d->hap_off[h]));
+    }
+    if (img_dw > 0xfffffff0ull) {
+        agx_set_error("packed image exceeds 16 GiB; split the batch");
+        return AGX_E_LIMIT;
+    }
+    PinBuf img_pin;
+    std::vector<uint32_t> img_heap;
+    struct ImgGuard {
+        PinBuf &p;
+        ~ImgGuard() { p.release(); }
+    } img_guard{img_pin};
+    uint32_t *img = nullptr;
+    if (ctx) {
+        rc = img_pin.alloc(ctx, img_dw * 4);
+        if (rc) return rc;
+        img = (uint32_t *)img_pin.p;
+    } else {
+        img_heap.resize(img_dw);
+        img = img_heap.data();
+    }
+    memset(img, 0, zero_dw * 4);
+    const bool have_tracks = d->read_bases && d->hap_bases && (probs || (d->q_base && d->q_ins && d->q_del && d->q_gcp));
+    if (!gen0.empty() && !have_tracks) {
+        agx_set_error("agx_phmm_batch_create: NULL track");
+        return AGX_E_ARG;
+    }
+    if (have_tracks) {
+        agx_parallel_for((int64_t)n_reads, 256, [&](int64_t ra, int64_t rz, int) {
+            for (int64_t r = ra; r < rz; ++r) {
+                const uint64_t o = d->read_off[r];
+                const size_t R = (size_t)(d->read_off[r + 1] - o), trk = (R + 3) / 4;
+                if (probs) {
+                    double *q = reinterpret_cast<double *>(img + read_dw[(size_t)r]);
+                    for (int k = 0; k < 4; ++k) memcpy(q + (size_t)k * R, prob[k] + o, R * sizeof(double));
+                    uint8_t *c = reinterpret_cast<uint8_t *>(q + 4 * R);
+                    memcpy(c, d->read_bases + o, R);
+                    memset(c + R, 0, trk * 4 - R);
+                } else {
+                    uint8_t *p = reinterpret_cast<uint8_t *>(img + read_dw[(size_t)r]);
+                    const uint8_t *src[5] = {d->read_bases, d->q_base, d->q_ins, d->q_del, d->q_gcp};
+                    for (int k = 0; k < 5; ++k) {
+                        memcpy(p + (size_t)k * trk * 4, src[k] + o, R);
+                        memset(p + (size_t)k * trk * 4 + R, 0, trk * 4 - R);
+                    }
+                }
+            }
+        });
+        agx_parallel_for((int64_t)n_haps, 256, [&](int64_t ha, int64_t hz, int) {
+            for (int64_t h = ha; h < hz; ++h) {
+                const uint64_t o = d->hap_off[h];
+                const size_t H = (size_t)(d->hap_off[h + 1] - o);
+                uint8_t *p = reinterpret_cast<uint8_t *>(img + hap_dw[(size_t)h]);
+                memcpy(p, d->hap_bases + o, H);
+                memset(p + H, 0, hap_block_dw(H) * 4 - H);
+            }
+        });
+    }
+    auto put_read = [&](uint32_t) {};
+    auto put_hap = [&](uint32_t) {};
 
     // ---- a plan: lane tilings, waves and records for one kernel family.
     // kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group.
@@ -343,6 +413,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         int64_t padded = 0;
     };
     auto make_plan = [&](int kind, int slots, bool rows_f64, PlanOut &po) -> int {
+        const double tm0 = now();
+        double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
         const ClassTable ct = class_table(kind);
         auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
         std::vector<Plan> gen = gen0;
@@ -386,6 +458,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             }
         };
         double beta = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
+        tm1 = now();
         tile_all(beta);
         // Tail regime (as in the SW planner): a batch whose waves fill the chip's resident capacity (3 waves
         // per SIMD for the packed kernel, 2 for the others) less than 1.6 times lasts as long as its longest
@@ -416,6 +489,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 }
             }
         }
+        tm2 = now();
         for (size_t gi = 0; gi < gen.size(); ++gi) {
             Plan &p = gen[gi];
             const uint16_t v = memo[p.R << 16 | p.th];
@@ -453,28 +527,20 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                         }
             }
         }
+        tm3 = now();
         // order: class, lanes per group (wide first), then long reads first, read, haplotype -- a wave's
         // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
         // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
+        std::vector<Plan> plan;
         {
             uint32_t max_r = 0;
             for (const Plan &p : gen) max_r = std::max(max_r, p.R);
-            std::vector<uint32_t> cnt((size_t)max_r + 2, 0);
-            for (const Plan &p : gen) ++cnt[(size_t)(max_r - p.R) + 1];
-            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-            std::vector<Plan> tmp(gen.size());
-            for (const Plan &p : gen) tmp[cnt[(size_t)(max_r - p.R)]++] = p;
-            gen.swap(tmp);
-        }
-        std::vector<Plan> plan(gen.size());
-        {
-            std::vector<uint32_t> cnt((size_t)ct.n * 64 + 1, 0);
-            auto bucket = [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); };
-            for (const Plan &p : gen) ++cnt[bucket(p) + 1];
-            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
-            for (const Plan &p : gen) plan[cnt[bucket(p)]++] = p;
+            std::vector<Plan> tmp;
+            counting_sort(gen, tmp, (size_t)max_r + 1, [&](const Plan &p) { return (size_t)(max_r - p.R); });
+            counting_sort(tmp, plan, (size_t)ct.n * 64 + 1, [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); });
         }
         std::vector<Plan>().swap(gen);
+        tm4 = now();
         size_t i = 0;
         while (i < plan.size()) {
             const int cls = plan[i].cls;
@@ -535,10 +601,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                         g.init32 = FLT_MAX / 16 / (float)p.H;
                         po.groups1.push_back(g);
                     }
-                    if (img.size() > 0xfffffff0ull) {
-                        agx_set_error("packed image exceeds 16 GiB; split the batch");
-                        return AGX_E_LIMIT;
-                    }
                     ++n;
                     ++i;
                 }
@@ -562,9 +624,13 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             }
             po.launches.push_back(cl);
         }
+        if (trace)
+            fprintf(stderr, "[phmm make_plan kind %d] copy+pairing %.2f, tiling %.2f, assign %.2f, sort %.2f, waves+image %.2f ms\n", kind,
+                    tm1 - tm0, tm2 - tm1, tm3 - tm2, tm4 - tm3, now() - tm4);
         return AGX_OK;
     };
 
+    if (trace) fprintf(stderr, "[phmm create] enumerate %.2f ms\n", now() - t_begin);
     PlanOut pmain, presc;
     rc = make_plan(precision, packed ? 2 : 1, f64, pmain);
     // a packed float batch cannot reuse its records for the double rescue pass: second plan
@@ -598,10 +664,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         stripe_lds = std::max(stripe_lds, ph_tab_bytes(true, gatk_prior, w.steps + 63u));
         const int64_t n_stripes = (p.H + 64 * stripe_cols() - 1) / (64 * stripe_cols());
         pstripe.padded += n_stripes * w.steps * 64 * stripe_cols();
-        if (img.size() > 0xfffffff0ull) {
-            agx_set_error("packed image exceeds 16 GiB; split the batch");
-            return AGX_E_LIMIT;
-        }
     }
     if (stripe_lds > 160 * 1024) {
         agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", stripe_lds);
@@ -634,7 +696,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
     b->info.padded_cells = padded;
-    b->info.input_bytes = (int64_t)(img.size() * 4 + groups_bytes + pmain.tabs.size() * sizeof(PhTab) +
+    b->info.input_bytes = (int64_t)(img_dw * 4 + groups_bytes + pmain.tabs.size() * sizeof(PhTab) +
                                     pmain.waves.size() * sizeof(PhWave));
     const bool two_pass = precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA;
     b->info.n_launches = (int32_t)(pmain.launches.size() + (packed ? presc.launches.size() : two_pass ? pmain.launches.size() : 0));
@@ -669,7 +731,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     } lut; // layout the launch code relies on: [lut_d][lut_f][mis_d][mis_f]
     build_lut(gatk_prior, lut.d, lut.f, lut.mis_d, lut.mis_f);
     std::vector<Piece> pieces;
-    pieces.push_back(Piece{&b->img, img.data(), img.size() * 4});
+    pieces.push_back(Piece{&b->img, nullptr, img_dw * 4}); // already in pinned memory (img_pin)
     pieces.push_back(Piece{&b->main.groups, packed ? (const void *)pmain.groups2.data() : (const void *)pmain.groups1.data(), groups_bytes});
     pieces.push_back(Piece{&b->main.tabs, pmain.tabs.data(), pmain.tabs.size() * sizeof(PhTab)});
     pieces.push_back(Piece{&b->main.waves, pmain.waves.data(), pmain.waves.size() * sizeof(PhWave)});
@@ -685,7 +747,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }
     pieces.push_back(Piece{&b->lut, &lut, sizeof lut});
     size_t stage_bytes = 0;
-    for (const Piece &pc : pieces) stage_bytes += (pc.bytes + 255) & ~(size_t)255;
+    for (const Piece &pc : pieces)
+        if (pc.src) stage_bytes += (pc.bytes + 255) & ~(size_t)255;
     PinBuf stage;
     struct StageGuard {
         PinBuf &s;
@@ -703,6 +766,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     {
         size_t at = 0;
         for (const Piece &pc : pieces) {
+            if (!pc.src) { // the image: built in its own pinned block
+                if (e == hipSuccess && pc.bytes) e = hipMemcpyAsync(pc.dst->p, img, pc.bytes, hipMemcpyHostToDevice, cs);
+                continue;
+            }
             if (pc.bytes) memcpy((char *)stage.p + at, pc.src, pc.bytes);
             if (e == hipSuccess && pc.bytes) e = hipMemcpyAsync(pc.dst->p, (char *)stage.p + at, pc.bytes, hipMemcpyHostToDevice, cs);
             at += (pc.bytes + 255) & ~(size_t)255;
@@ -718,7 +785,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }
     if (trace)
         fprintf(stderr, "[agx_phmm_batch_create] %lld pairs: plan+order %.2f ms, waves+pack %.2f ms, alloc+H2D %.2f ms (%.1f MB)\n",
-                (long long)n_pairs, t_plan - t_begin, t_pack - t_plan, now() - t_pack, img.size() * 4 / 1e6);
+                (long long)n_pairs, t_plan - t_begin, t_pack - t_plan, now() - t_pack, img_dw * 4 / 1e6);
     *out = b;
     b = nullptr;
     return AGX_OK;
@@ -876,7 +943,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
-    agx_parallel_for(b->n_pairs, 8192, [&](int64_t lo, int64_t hi, int) {
+    agx_parallel_for(b->n_pairs, 2048, [&](int64_t lo, int64_t hi, int) {
         for (int64_t k = lo; k < hi; ++k) {
             double v = s[k];
             if (f32) {

@@ -32,10 +32,13 @@ struct Pool {
 
     Pool()
     {
-        // 8 parts are plenty for byte shuffling and counting sorts; AGX_HOST_THREADS (tuning build) overrides
+        // At most 16 parts (a GPU box gives one rank 16 cores; counting sorts and the final log10 loop stop
+        // scaling about there), never more than half the machine so that 8 ranks do not oversubscribe it;
+        // AGX_HOST_THREADS (tuning build) overrides
         const char *e = agx_tune("AGX_HOST_THREADS");
         int n = e ? atoi(e) : 0;
-        if (n <= 0) n = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        if (n <= 0) n = (int)std::min(16u, std::max(hw >= 32 ? hw / 8 : hw, 1u));
         parts = n;
         try {
             for (int k = 0; k + 1 < n; ++k) workers.emplace_back([this] { loop(); });
@@ -510,6 +513,25 @@ int agx_ctx_timer_stop(agx_ctx *c, float *ms)
     int rc = agx_bind(c);
     if (rc) return rc;
     AGX_HIP(hipEventRecord(c->ev1, c->stream));
+    AGX_HIP(hipEventSynchronize(c->ev1));
+    float t = 0;
+    AGX_HIP(hipEventElapsedTime(&t, c->ev0, c->ev1));
+    if (ms) *ms = t;
+    return AGX_OK;
+}
+
+int agx_ctx_timer_mark(agx_ctx *c)
+{
+    int rc = agx_bind(c);
+    if (rc) return rc;
+    AGX_HIP(hipEventRecord(c->ev1, c->stream));
+    return AGX_OK;
+}
+
+int agx_ctx_timer_elapsed(agx_ctx *c, float *ms)
+{
+    int rc = agx_bind(c);
+    if (rc) return rc;
     AGX_HIP(hipEventSynchronize(c->ev1));
     float t = 0;
     AGX_HIP(hipEventElapsedTime(&t, c->ev0, c->ev1));

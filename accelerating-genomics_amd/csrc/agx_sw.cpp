@@ -227,36 +227,6 @@ struct Bucket {
     int cls = 0, G = 0;
 };
 
-// Stable counting sort of src into dst by key(e) in [0, n_keys), threaded: every part counts its
-// contiguous chunk, the offsets are laid out key-major / part-minor, every part scatters its chunk in order.
-template <typename T, typename KeyFn>
-void counting_sort(const std::vector<T> &src, std::vector<T> &dst, size_t n_keys, KeyFn key)
-{
-    const size_t n = src.size();
-    dst.resize(n);
-    const int parts = (int)std::min<int64_t>(agx_host_threads(), std::max<int64_t>(1, (int64_t)n / 32768));
-    std::vector<std::vector<uint32_t>> cnt((size_t)parts);
-    const size_t chunk = (n + parts - 1) / (size_t)parts;
-    agx_pool_run(parts, [&](int t) {
-        std::vector<uint32_t> &c = cnt[(size_t)t];
-        c.assign(n_keys, 0);
-        const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
-        for (size_t i = b; i < e; ++i) ++c[key(src[i])];
-    });
-    uint32_t run = 0;
-    for (size_t k = 0; k < n_keys; ++k)
-        for (int t = 0; t < parts; ++t) {
-            const uint32_t c = cnt[(size_t)t][k];
-            cnt[(size_t)t][k] = run;
-            run += c;
-        }
-    agx_pool_run(parts, [&](int t) {
-        std::vector<uint32_t> &c = cnt[(size_t)t];
-        const size_t b = std::min(n, (size_t)t * chunk), e = std::min(n, b + chunk);
-        for (size_t i = b; i < e; ++i) dst[c[key(src[i])]++] = src[i];
-    });
-}
-
 inline double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -4,30 +4,40 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Headline (`value`): Smith-Waterman GCUPS on BASELINE config 2 -- per GPU one batch of 65 536
-pairs, 150x150, iid ACGT + 25 % related pairs, int32 affine-gap scores (computed in packed int16
-lanes, bit-identical) -- with the packed batch
-already resident in HBM when the clock starts.  A step is one pass of the fill over that batch
-(agx_sw_batch_launch).  GCUPS counts len_a*len_b with the newline sentinel excluded:
-22 500 cells per pair although the kernel fills 151x151.
+A STEP is one pass of the hot path over one batch in the reference's own timing window
+(smithWaterman/hipvers.cpp:475-483): kernel launch -> results resident in HOST memory, with
+the inputs already resident in HBM when the clock starts.  Every step is clocked on its own (median and
+min are reported beside the mean); the launch inside it is bracketed by HIP events on the launch stream
+(kernel-only duration, the roofline's denominator).  Before the W untimed warm-up steps the device is
+warmed BY TIME (--warm-seconds of back-to-back launches), so a short run (--steps 20) and a long one
+(--steps 500) report the same figures.
 
-Second leg, same JSON line under "pairhmm": BASELINE config 3 -- 65 536 (read, haplotype) pairs,
-R=100, H=300, fp32 forward (AGX_PHMM_F32_FMA: packed FMA, two haplotypes per lane group) with
-double rescue of underflowing pairs -- in pairs/s.
+Headline (`value`): Smith-Waterman GCUPS on BASELINE config 2 -- per GPU one batch of 65 536 pairs, 150x150,
+iid ACGT + 25 % related pairs, int32 affine-gap scores computed in packed int16 lanes (bit-identical; the
+"sw_int32" leg times the int32 kernel on the same batch).  GCUPS counts len_a*len_b with the newline
+sentinel excluded: 22 500 cells per pair although the kernel fills 151x151.
 
-"config4" / "config5": the two 8-GPU configs of BASELINE.json at one GPU's 1/8 shard (131 072 mixed SW
-pairs; 32 768 PairHMM pairs R=250 H=500 in bit-identical fp64), a tenth of the steps each.
+"pairhmm": BASELINE config 3 -- 65 536 (read, haplotype) pairs, R=100, H=300, fp32 forward (packed FMA, two
+haplotypes per lane group) with double rescue of underflowing pairs -- in pairs/s, same window.
 
-N > 1: every rank owns its own batch of the same shape (independent pairs shard with no
-collective), so scaling is "weak"; torch.distributed (RCCL) is used only for the
-barriers and the max-over-ranks of the timed region.
+"config4" / "config5": the two 8-GPU configs of BASELINE.json.  Weak leg: every rank its own 1/8-size shard
+(131 072 mixed SW pairs; 32 768 PairHMM pairs R=250 H=500 in bit-identical fp64).  "total" (strong scaling):
+ONE host batch of the full size (1 048 576 pairs; 262 144 pairs), identical on every rank, cut into
+world-size contiguous shards by cells exactly as agx_*_devices cut (agx_sw_shard_cuts / agx_phmm_shard_cuts);
+every rank fills its shard, the clock is the max over ranks; "per_rank" lists each shard's cells and launch
+time.  "multi_one_process": the same batch through agx_*_multi(N) from rank 0 alone, host buffers in, results
+out (needs all N devices visible to rank 0; skipped otherwise).
 
-"roofline": HBM bound as BASELINE.json asks; achieved = algorithmic bytes of one launch
-(304 B/pair SW, 808 B/pair PairHMM) / mean launch duration from HIP events on
-the launch stream.  These kernels are VALU-bound by construction, so the fraction is tiny; the
-"valu" sub-object prices the same launch against the integer/fp32 vector issue rate.
-"cpu_baseline": the reference C program itself (oracle/_ref, compiled in the authoring
-container from the unmodified sources) when present, else the oracle's C port, one core.
+"one_shot": host-inclusive calls (agx_sw_score / agx_phmm_forward: plan + H2D + fill + D2H) on config 2 / 3,
+pageable and page-locked source buffers.  Never the headline.
+
+"roofline": HBM bound as BASELINE.json asks; achieved = algorithmic bytes of one launch (304 B/pair SW,
+808 / 1758 B/pair PairHMM) / the launch's mean duration from the HIP events of the timed
+steps.  These kernels are VALU-bound by construction, so the fraction is tiny; "valu" prices the same
+launch against the measured vector issue rate.  "traffic" is NOT measured in this run: it is the PMC figure
+of the rocprofv3 pass named in "traffic_source".
+"cpu_baseline": the reference C program itself (oracle/_ref, compiled in the authoring container from the
+unmodified sources) when present, else the oracle's C port; one core, a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -47,18 +57,20 @@ PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H = 64, 64, 16, 100, 300
 C4_PAIRS = 1 << 20                                                  # config 4, all 8 GPUs together
 C5_REGIONS, C5_READS, C5_HAPS, C5_R, C5_H = 512, 32, 16, 250, 500   # config 5 (262 144 pairs), all 8 GPUs together
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# Measured wave64 issue rates on this chip (tools/valu_microbench.hip, profiles/r01_valu_microbench.log):
-# add/xor/mul class ~65 T lane-op/s; max/max3/cndmask/compare/DPP/fma/f64 class ~38 T lane-op/s.
-# packed (v_pk_*) instructions ~37.5 T lane-instr/s = 75 T element-op/s.
-VALU_FAST, VALU_SLOW, VALU_PACKED = 65e12, 38e12, 37.5e12
+# Measured wave64 issue cost on this chip (tools/valu_microbench2.hip, profiles/r02_valu_microbench2.log): every
+# v_pk_* instruction 4.2 cycles per SIMD; v_add/sub/xor_u32 2.4 in a pure stream but 4.2 beside packed ones
+# (profiles/r02_valu_microbench3.log), so every instruction of the cell is priced at the packed rate.
+VALU_PACKED, VALU_SLOW = 37.5e12, 38e12  # lane-instructions / s
+WINDOW = "kernel launch -> results resident in host memory, inputs resident in HBM (hipvers.cpp:475-483)"
 
 
-def cpu_baseline_sw(n_pairs):
-    """Time the reference SW program (or the oracle port) on the first n_pairs of the rank-0 workload."""
+# ----------------------------------------------------------------------------------------- CPU baselines
+
+def _sw_ref_or_port(b, label):
+    """Time the reference SW program (or the oracle port) on batch b, one core."""
     import accelerating_genomics_amd.synth as synth
 
-    b = synth.sw_pairs(n_pairs, SW_LEN, SW_LEN, seed=2, related_frac=0.25)
-    cells = n_pairs * SW_LEN * SW_LEN
+    cells = b.cells(sentinel=False)
     ref = os.path.join(ROOT, "oracle", "_ref", "sw_ref")
     if os.access(ref, os.X_OK):
         with tempfile.TemporaryDirectory() as d:
@@ -67,8 +79,8 @@ def cpu_baseline_sw(n_pairs):
             t0 = time.perf_counter()
             out = subprocess.run([ref, path], capture_output=True, check=True)
             dt = time.perf_counter() - t0
-        assert out.stdout.count(b"Score:") == n_pairs
-        kind = "reference"
+        assert out.stdout.count(b"Score:") == b.n_pairs
+        kind, what = "reference", "antidiagonalSmithWaterman.c incl. its text parsing"
     else:
         from tests import oracle_api
 
@@ -76,9 +88,8 @@ def cpu_baseline_sw(n_pairs):
         t0 = time.perf_counter()
         orc.sw_batch(b, 0)
         dt = time.perf_counter() - t0
-        kind = "port"
-    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
-            "sample": "%d of the 65536 config-2 pairs, antidiagonalSmithWaterman.c incl. its text parsing, %.1f s" % (n_pairs, dt)}
+        kind, what = "port", "oracle anti-diagonal port"
+    return {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind, "sample": "%s, %s, %.1f s" % (label, what, dt)}
 
 
 def cpu_baseline_sw_multicore(n_procs, pairs_each):
@@ -104,10 +115,9 @@ def cpu_baseline_sw_multicore(n_procs, pairs_each):
             "sample": "%d concurrent copies of antidiagonalSmithWaterman.c, %d pairs each, %.1f s" % (n_procs, pairs_each, dt)}
 
 
-def cpu_baseline_phmm(n_regions):
+def _phmm_ref_or_port(p, label):
     import accelerating_genomics_amd.synth as synth
 
-    p = synth.phmm_regions(n_regions, PH_READS, PH_HAPS, PH_R, PH_H, seed=3)
     ref = os.path.join(ROOT, "oracle", "_ref", "phmm_matrix_ref")
     if os.access(ref, os.X_OK):
         with tempfile.TemporaryDirectory() as d:
@@ -125,18 +135,18 @@ def cpu_baseline_phmm(n_regions):
         orc.phmm_batch(p, 1)
         dt = time.perf_counter() - t0
         kind, what = "port", "oracle antidiag port (fp64)"
-    return {"value": p.n_pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
-            "sample": "%d of the 65536 config-3 pairs, %s, %.1f s" % (p.n_pairs, what, dt)}
+    return {"value": p.n_pairs / dt, "unit": "pairs/s", "cores": 1, "kind": kind, "gcups": p.cells() / dt / 1e9,
+            "sample": "%s, %s, %.1f s" % (label, what, dt)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warm-seconds", type=float, default=0.5, help="back-to-back launches before every timed leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=32768)
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config 4 / config 5 legs (PMC profiling passes)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="headline legs only (PMC profiling passes)")
     # rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (never for numbers):
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="map every rank to device 0")
@@ -159,12 +169,26 @@ def main():
     local_rank %= agx.device_count()
     torch.cuda.set_device(local_rank)
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+    cpu_group = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+        # Gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE
+        # JSON line and nothing else, so file descriptor 1 points at stderr while the groups come up.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                cpu_group = dist.new_group(backend="gloo")  # waits that must not park a kernel on the GPUs
+                dist.barrier(group=cpu_group)
+            else:
+                dist.init_process_group("gloo")
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     n_gpus = world if multi else 1
     if args.gpus != n_gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE %d; reporting n_gpus=%d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -177,73 +201,45 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
-    def timed(dev):
-        for _ in range(args.warmup):
+    def warm(dev):
+        """Clocks and queues settle over a few hundred ms of work: warm by time, not by count."""
+        t_end = time.perf_counter() + args.warm_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                dev.launch()
+            ctx.sync()
+
+    def timed(dev, fetch, steps, warmup):
+        """-> dict: wall clock over `steps` steps (max over ranks), per-step host times, per-step kernel times, and
+        the kernel-only figure from back-to-back launches."""
+        warm(dev)
+        for _ in range(warmup):
             dev.launch()
+            fetch()
+        per = np.empty(steps)
+        kern = np.empty(steps)
         barrier()
         t0 = time.perf_counter()
-        ctx.timer_start()
-        for _ in range(args.steps):
+        for k in range(steps):
+            ta = time.perf_counter()
+            ctx.timer_start()
             dev.launch()
-        ev_ms = ctx.timer_stop()  # HIP events on the launch stream (also drains it)
+            ctx.timer_mark()
+            fetch()  # waits for the stream, copies the results into host memory
+            per[k] = time.perf_counter() - ta
+            kern[k] = ctx.timer_elapsed()  # HIP events around the launch on its stream; no extra wait
         barrier()
-        dt = time.perf_counter() - t0
-        return agd.max_over_ranks(dt, device=red_dev), ev_ms / args.steps
+        dt = agd.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+        ctx.timer_start()
+        for _ in range(steps):
+            dev.launch()
+        b2b = ctx.timer_stop() / steps
+        return {"dt": dt, "steps": steps, "step_ms": {"median": float(np.median(per)) * 1e3, "min": float(per.min()) * 1e3,
+                                                     "mean": float(per.mean()) * 1e3, "max": float(per.max()) * 1e3},
+                "launch_ms": float(kern.mean()), "launch_ms_min": float(kern.min()), "back_to_back_launch_ms": b2b}
 
-    # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
-    sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
-    sw_dev = ctx.sw_batch(sw)
-    sw_info = sw_dev.info()
-    sw_dt, sw_launch_ms = timed(sw_dev)
-    sw_scores = sw_dev.scores()
-    sw_cells = sw.cells(sentinel=False)  # 65536 * 22500
-    sw_gcups = n_gpus * sw_cells * args.steps / sw_dt / 1e9
-    sw_bytes = sw.algorithmic_bytes()  # 304 B/pair
-    sw_dev.close()
-
-    # ---------------- PairHMM, BASELINE config 3
-    ph = synth.phmm_regions(PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H, seed=3 + 1000 * rank)
-    ph_dev = ctx.phmm_batch(ph, agx.PHMM_F32_FMA)
-    ph_info = ph_dev.info()
-    ph_dt, ph_launch_ms = timed(ph_dev)
-    ph_l, _ = ph_dev.results()
-    ph_rescued = ph_dev.info().n_rescued
-    ph_rate = n_gpus * ph.n_pairs * args.steps / ph_dt
-    ph_bytes = ph.algorithmic_bytes()  # 808 B/pair
-    ph_dev.close()
-
-    # ---------------- the two 8-GPU configs of BASELINE.json, each rank its 1/8 shard (a tenth of the steps)
-    def timed_few(dev):
-        keep = args.steps, args.warmup
-        args.steps, args.warmup = max(10, keep[0] // 10), max(2, keep[1] // 10)
-        try:
-            dt, launch_ms = timed(dev)
-            return dt, launch_ms, args.steps
-        finally:
-            args.steps, args.warmup = keep
-
-    extra = not args.no_extra_configs
-    if extra:
-        c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
-        c4_dev = ctx.sw_batch(c4)
-        c4_info = c4_dev.info()
-        c4_dt, c4_ms, c4_steps = timed_few(c4_dev)
-        c4_sum = int(c4_dev.scores().astype(np.int64).sum())
-        c4_dev.close()
-        c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
-        c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
-        c5_info = c5_dev.info()
-        c5_dt, c5_ms, c5_steps = timed_few(c5_dev)
-        c5_l, _ = c5_dev.results()
-        c5_dev.close()
-
-    if rank != 0:
-        if multi:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    traffic = None
+    few = lambda: (max(10, args.steps // 10), max(2, args.warmup // 10))
+    traffic = {}
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         traffic = json.load(open(tfile))
@@ -251,53 +247,208 @@ def main():
     def roof(alg_bytes, launch_ms, key):
         ach = alg_bytes / (launch_ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get(key), "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes}
+                "traffic": traffic.get(key), "traffic_source": traffic.get("_source") if traffic.get(key) is not None else None,
+                "launch_ms": launch_ms, "algorithmic_bytes_per_launch": alg_bytes}
 
+    def leg(t, units, per_unit_name):
+        """Throughput fields of one leg: whole-job units over the max-over-ranks wall clock of its steps."""
+        return {"value": n_gpus * units * t["steps"] / t["dt"], "steps": t["steps"], "ms_per_step": t["dt"] / t["steps"] * 1e3,
+                "step_ms": t["step_ms"], "window": WINDOW,
+                "kernel_only": {per_unit_name: n_gpus * units / (t["back_to_back_launch_ms"] * 1e-3),
+                                "launch_ms": t["back_to_back_launch_ms"], "what": "back-to-back launches, HIP events, results stay in HBM"}}
+
+    # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
+    sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
+    sw_out = np.empty(sw.n_pairs, np.int32)
+    sw_dev = ctx.sw_batch(sw)
+    sw_info = sw_dev.info()
+    sw_t = timed(sw_dev, lambda: sw_dev.scores(sw_out), args.steps, args.warmup)
+    sw_sum = int(sw_out.astype(np.int64).sum())
+    sw_dev.close()
+    sw_cells = sw.cells(sentinel=False)  # 65536 * 22500
+    # the same batch through the int32 kernel (BASELINE config 2 as worded); scores must be the same
+    ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_INT32)
+    i32_dev = ctx.sw_batch(sw)
+    ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_AUTO)
+    i32_info = i32_dev.info()
+    i32_out = np.empty(sw.n_pairs, np.int32)
+    i32_t = timed(i32_dev, lambda: i32_dev.scores(i32_out), *few())
+    i32_same = bool(np.array_equal(i32_out, sw_out))
+    i32_dev.close()
+
+    # ---------------- PairHMM, BASELINE config 3
+    ph = synth.phmm_regions(PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H, seed=3 + 1000 * rank)
+    ph_out = (np.empty(ph.n_pairs), np.empty(ph.n_pairs))
+    ph_dev = ctx.phmm_batch(ph, agx.PHMM_F32_FMA)
+    ph_info = ph_dev.info()
+    ph_t = timed(ph_dev, lambda: ph_dev.results(ph_out), args.steps, args.warmup)
+    ph_rescued = ph_dev.info().n_rescued
+    ph_sum = float(ph_out[0].sum())
+    ph_dev.close()
+
+    extra = not args.no_extra_configs
+    if extra:
+        # ---------------- weak legs of the two 8-GPU configs: every rank its own 1/8-size shard
+        c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
+        c4_out = np.empty(c4.n_pairs, np.int32)
+        c4_dev = ctx.sw_batch(c4)
+        c4_info = c4_dev.info()
+        c4_t = timed(c4_dev, lambda: c4_dev.scores(c4_out), *few())
+        c4_sum = int(c4_out.astype(np.int64).sum())
+        c4_dev.close()
+        c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
+        c5_out = (np.empty(c5.n_pairs), np.empty(c5.n_pairs))
+        c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
+        c5_info = c5_dev.info()
+        c5_t = timed(c5_dev, lambda: c5_dev.results(c5_out), *few())
+        c5_sum = float(c5_out[0].sum())
+        c5_dev.close()
+
+        # ---------------- strong legs: ONE host batch of the full size, the same on every rank, cut by cells
+        def per_rank_table(pairs, cells, t):
+            """Every rank's shard and launch time, gathered to all ranks (6 numbers each)."""
+            mine = torch.tensor([rank, pairs, cells, t["launch_ms"], t["launch_ms_min"], t["step_ms"]["median"]], dtype=torch.float64,
+                                device=red_dev)
+            rows = [torch.zeros_like(mine) for _ in range(world)] if multi else [mine]
+            if multi:
+                dist.all_gather(rows, mine)
+            return [{"rank": int(r[0]), "pairs": int(r[1]), "cells": int(r[2]), "launch_ms": float(r[3]), "launch_ms_min": float(r[4]),
+                     "step_ms_median": float(r[5])} for r in (x.cpu() for x in rows)]
+
+        c4f = synth.sw_pairs(C4_PAIRS, 32, 512, seed=4)
+        cut4 = agx.sw_shard_cuts(c4f, world)
+        mine4 = c4f.subset(np.arange(cut4[rank], cut4[rank + 1]))
+        s4_out = np.empty(mine4.n_pairs, np.int32)
+        s4_dev = ctx.sw_batch(mine4)
+        s4_info = s4_dev.info()
+        s4_t = timed(s4_dev, lambda: s4_dev.scores(s4_out), *few())
+        s4_dev.close()
+        s4_rows = per_rank_table(mine4.n_pairs, mine4.cells(sentinel=False), s4_t)
+        c5f = synth.phmm_regions(C5_REGIONS, C5_READS, C5_HAPS, C5_R, C5_H, seed=5)
+        cut5 = agx.phmm_shard_cuts(c5f, world)
+        mine5 = c5f.regions(int(cut5[rank]), int(cut5[rank + 1]))
+        s5_out = (np.empty(mine5.n_pairs), np.empty(mine5.n_pairs))
+        s5_dev = ctx.phmm_batch(mine5, agx.PHMM_F64)
+        s5_t = timed(s5_dev, lambda: s5_dev.results(s5_out), *few())
+        s5_dev.close()
+        s5_rows = per_rank_table(mine5.n_pairs, mine5.cells(), s5_t)
+        # ... and through ONE process driving all the devices (agx_*_multi): rank 0 alone, the others wait on the CPU
+        multi_one = {"skipped": "rank 0 sees %d device(s), %d needed" % (agx.device_count(), world)}
+        if multi:
+            dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+        if rank == 0 and agx.device_count() >= world and not args.share_device:
+            def best_of(fn, reps=3):
+                fn()  # contexts of the other devices, their pools
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts), float(np.median(ts))
+            t_sw, t_sw_med = best_of(lambda: agx.sw_score_multi(c4f, world))
+            t_ph, t_ph_med = best_of(lambda: agx.phmm_forward_multi(c5f, agx.PHMM_F64, world))
+            multi_one = {"n_devices": world, "what": "agx_sw_score_multi / agx_phmm_forward_multi from one process: host buffers in, results out "
+                         "(plan + H2D + fill + D2H per device), best of 3",
+                         "config4": {"ms": t_sw * 1e3, "ms_median": t_sw_med * 1e3, "gcups_host_inclusive": c4f.cells(sentinel=False) / t_sw / 1e9},
+                         "config5": {"ms": t_ph * 1e3, "ms_median": t_ph_med * 1e3, "pairs_per_s_host_inclusive": c5f.n_pairs / t_ph}}
+        if multi:
+            dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
+
+    # ---------------- host-inclusive one-shot calls (rank 0 reports its own; never the headline)
+    def one_shot(fn, reps):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return {"ms_median": float(np.median(ts)) * 1e3, "ms_min": min(ts) * 1e3, "reps": reps}
+
+    if extra and rank == 0:
+        reps = few()[0]
+        pinned = synth.SWBatch(agx.host_array(sw.bases.size, np.uint8), agx.host_array(sw.off.size, np.uint64), agx.host_array(sw.len.size, np.uint32))
+        pinned.bases[:], pinned.off[:], pinned.len[:] = sw.bases, sw.off, sw.len
+        os_sw, os_sw_pin = one_shot(lambda: ctx.sw_score(sw), reps), one_shot(lambda: ctx.sw_score(pinned), reps)
+        os_ph = one_shot(lambda: ctx.phmm_forward(ph, agx.PHMM_F32_FMA), reps)
+        one = {"what": "agx_sw_score / agx_phmm_forward: host buffers in, results out (plan + H2D + fill + D2H); PCIe-inclusive, never the headline",
+               "config2_pageable": dict(os_sw, gcups=sw_cells / (os_sw["ms_min"] * 1e-3) / 1e9),
+               "config2_pinned": dict(os_sw_pin, gcups=sw_cells / (os_sw_pin["ms_min"] * 1e-3) / 1e9),
+               "config3_pageable": dict(os_ph, pairs_per_s=ph.n_pairs / (os_ph["ms_min"] * 1e-3))}
+
+    if rank != 0:
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    sw_leg = leg(sw_t, sw_cells / 1e9, "gcups")
+    ph_leg = leg(ph_t, ph.n_pairs, "pairs_per_s")
+    i32_leg = leg(i32_t, sw_cells / 1e9, "gcups")
     out = {
         "metric": "Smith-Waterman affine-gap score-only GCUPS (config 2: 65536 pairs 150x150 per GPU)",
-        "value": sw_gcups, "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": sw_dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": sw_leg["value"], "unit": "GCUPS", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sw_leg["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int16x2 lanes, int32 scores", "data": "synthetic",
         "config": {"workload": "BASELINE config 2: 65536 SW pairs 150x150 per GPU, iid ACGT + 25% related, newline sentinel aligned as the reference does",
                    "pairs_per_gpu": SW_PAIRS, "len": SW_LEN, "cells_counted_per_pair": SW_LEN * SW_LEN,
-                   "parallelism": "pairs sharded per GPU, no collective"},
-        "roofline": roof(sw_bytes, sw_launch_ms, "sw_fill"),
+                   "parallelism": "pairs sharded per GPU, no collective", "window": WINDOW,
+                   "warm_seconds_before_each_leg": args.warm_seconds},
+        "step_ms": sw_leg["step_ms"], "kernel_only": sw_leg["kernel_only"],
+        "roofline": roof(sw.algorithmic_bytes(), sw_t["launch_ms"], "sw_fill"),
         "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
                "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
-               "valu": {"ops_per_cell": "12 packed int16 instructions per 2 cells (v_pk_add/max/min_u16/sub_u16 clamp + xor)",
-                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (6.0 / VALU_PACKED) / (sw_launch_ms * 1e-3)},
-               "score_checksum": int(sw_scores.astype(np.int64).sum())},
-        "pairhmm": {
-            "metric": "PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)",
-            "value": ph_rate, "unit": "pairs/s", "ms_per_step": ph_dt / args.steps * 1e3, "dtype": "f32 (two haplotypes per lane group, packed FMA; double rescue)",
-            "gcups": n_gpus * ph.cells() * args.steps / ph_dt / 1e9, "rescued_in_f64": int(ph_rescued),
-            "waves": ph_info.n_waves, "launches_per_step": ph_info.n_launches,
-            "useful_cell_fraction": ph_info.cells / max(1, ph_info.padded_cells),
-            "roofline": roof(ph_bytes, ph_launch_ms, "phmm_fill"),
-            "valu": {"ops_per_cell": "8 packed fp32 instructions + 2 compares + 2 selects per 2 cells",
-                     "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (4 / VALU_PACKED + 2 / VALU_SLOW) / (ph_launch_ms * 1e-3)},
-            "log10_checksum": float(ph_l.sum()),
-        },
+               "valu": {"ops_per_cell": "10.5 instructions per 2 cells: 4.5 packed (v_pk_maximum3_f16 x2.5, v_pk_max_u16, v_pk_min_u16) + 6 32-bit add/sub/xor",
+                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (10.5 / 2 / VALU_PACKED) / (sw_t["launch_ms"] * 1e-3)},
+               "score_checksum": sw_sum},
+        "sw_int32": dict(i32_leg, metric="config 2 through the int32 kernel (one pair per lane group, AGX_SW_KERNEL_INT32)", unit="GCUPS",
+                         scores_identical_to_packed=i32_same, useful_cell_fraction=i32_info.cells / max(1, i32_info.padded_cells),
+                         roofline=roof(sw.algorithmic_bytes(), i32_t["launch_ms"], None)),
+        "pairhmm": dict(ph_leg, metric="PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)", unit="pairs/s",
+                        dtype="f32 (two haplotypes per lane group, packed FMA; double rescue)",
+                        gcups=n_gpus * ph.cells() * ph_t["steps"] / ph_t["dt"] / 1e9, rescued_in_f64=int(ph_rescued),
+                        waves=ph_info.n_waves, launches_per_step=ph_info.n_launches,
+                        useful_cell_fraction=ph_info.cells / max(1, ph_info.padded_cells),
+                        roofline=roof(ph.algorithmic_bytes(), ph_t["launch_ms"], "phmm_fill"),
+                        valu={"ops_per_cell": "8 packed fp32 instructions + 2 compares + 2 selects per 2 cells",
+                              "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (4 / VALU_PACKED + 2 / VALU_SLOW) / (ph_t["launch_ms"] * 1e-3)},
+                        log10_checksum=ph_sum),
     }
     if extra:
-        out["config4"] = {
-            "metric": "Smith-Waterman GCUPS, mixed lengths 32-512 (config 4: 1 048 576 pairs over 8 GPUs; %d pairs per GPU here)" % (C4_PAIRS // 8),
-            "value": n_gpus * c4.cells(sentinel=False) * c4_steps / c4_dt / 1e9, "unit": "GCUPS", "steps": c4_steps,
-            "ms_per_step": c4_dt / c4_steps * 1e3, "launch_ms": c4_ms, "launches_per_step": c4_info.n_launches,
-            "useful_cell_fraction": c4_info.cells / max(1, c4_info.padded_cells), "score_checksum": c4_sum}
-        out["config5"] = {
-            "metric": "PairHMM forward pairs/s, fp64 in the reference's operation order (config 5: 262 144 pairs R=250 H=500 over 8 GPUs; %d pairs per GPU here)" % c5.n_pairs,
-            "value": n_gpus * c5.n_pairs * c5_steps / c5_dt, "unit": "pairs/s", "dtype": "f64", "steps": c5_steps,
-            "ms_per_step": c5_dt / c5_steps * 1e3, "launch_ms": c5_ms, "gcups": n_gpus * c5.cells() * c5_steps / c5_dt / 1e9,
-            "launches_per_step": c5_info.n_launches, "useful_cell_fraction": c5_info.cells / max(1, c5_info.padded_cells),
-            "log10_checksum": float(c5_l.sum())}
+        c4_leg, c5_leg = leg(c4_t, c4.cells(sentinel=False) / 1e9, "gcups"), leg(c5_t, c5.n_pairs, "pairs_per_s")
+
+        def strong(t, rows, total_units, unit_name, cells_key):
+            cells = np.array([r["cells"] for r in rows], dtype=np.float64)
+            return {"value": total_units * t["steps"] / t["dt"], "unit": unit_name, "steps": t["steps"], "ms_per_step": t["dt"] / t["steps"] * 1e3,
+                    "window": WINDOW, "scaling": "strong", "n_shards": len(rows),
+                    "shard_cell_imbalance": float(cells.max() / cells.mean()) if cells.size and cells.mean() > 0 else None,
+                    "launch_ms_min_over_ranks": min(r["launch_ms"] for r in rows), "launch_ms_max_over_ranks": max(r["launch_ms"] for r in rows)}
+
+        out["config4"] = dict(c4_leg, metric="Smith-Waterman GCUPS, mixed lengths 32-512 (config 4: 1 048 576 pairs over 8 GPUs; weak leg: %d pairs per GPU)" % (C4_PAIRS // 8),
+                              unit="GCUPS", launches_per_step=c4_info.n_launches, useful_cell_fraction=c4_info.cells / max(1, c4_info.padded_cells),
+                              score_checksum=c4_sum, roofline=roof(c4.algorithmic_bytes(), c4_t["launch_ms"], None),
+                              total=dict(strong(s4_t, s4_rows, c4f.cells(sentinel=False) / 1e9, "GCUPS", "cells"),
+                                         workload="ONE batch of 1 048 576 pairs U[32,512] cut into %d shards by cells (agx_sw_shard_cuts)" % world,
+                                         launches_per_step_rank0=s4_info.n_launches, useful_cell_fraction_rank0=s4_info.cells / max(1, s4_info.padded_cells)),
+                              per_rank=s4_rows)
+        out["config5"] = dict(c5_leg, metric="PairHMM forward pairs/s, fp64 in the reference's operation order (config 5: 262 144 pairs R=250 H=500 over 8 GPUs; weak leg: %d pairs per GPU)" % c5.n_pairs,
+                              unit="pairs/s", dtype="f64", gcups=n_gpus * c5.cells() * c5_t["steps"] / c5_t["dt"] / 1e9,
+                              launches_per_step=c5_info.n_launches, useful_cell_fraction=c5_info.cells / max(1, c5_info.padded_cells),
+                              log10_checksum=c5_sum, roofline=roof(c5.algorithmic_bytes(), c5_t["launch_ms"], None),
+                              total=dict(strong(s5_t, s5_rows, c5f.n_pairs, "pairs/s", "cells"),
+                                         workload="ONE batch of 262 144 pairs R=250 H=500 (512 regions) cut into %d shards of whole regions by cells (agx_phmm_shard_cuts)" % world),
+                              per_rank=s5_rows)
+        out["multi_one_process"] = multi_one
+        out["one_shot"] = one
     if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
-        out["cpu_baseline"] = cpu_baseline_sw(args.cpu_sample_pairs)
-        out["pairhmm"]["cpu_baseline"] = cpu_baseline_phmm(max(1, args.cpu_sample_pairs // (PH_READS * PH_HAPS)))
+        out["cpu_baseline"] = _sw_ref_or_port(synth.sw_pairs(16384, SW_LEN, SW_LEN, seed=2, related_frac=0.25), "16384 of the 65536 config-2 pairs")
         out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        multi_cpu = cpu_baseline_sw_multicore(min(16, os.cpu_count() or 1), 8192)
+        out["pairhmm"]["cpu_baseline"] = _phmm_ref_or_port(synth.phmm_regions(8, PH_READS, PH_HAPS, PH_R, PH_H, seed=3), "8192 of the 65536 config-3 pairs")
+        multi_cpu = cpu_baseline_sw_multicore(min(16, os.cpu_count() or 1), 4096)
         if multi_cpu:
             out["cpu_baseline_multicore"] = multi_cpu
+        if extra:
+            out["config4"]["cpu_baseline"] = _sw_ref_or_port(synth.sw_pairs(4096, 32, 512, seed=4), "4096 config-4 pairs (lengths U[32,512])")
+            out["config5"]["cpu_baseline"] = _phmm_ref_or_port(synth.phmm_regions(8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5), "4096 config-5 pairs (R=250 H=500)")
     print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

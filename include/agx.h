@@ -88,7 +88,12 @@ void *agx_host_alloc(size_t bytes); /* NULL on failure */
 void agx_host_free(void *p);
 /* HIP-event stopwatch on the context's stream (used by bench.py for the roofline figures). */
 int agx_ctx_timer_start(agx_ctx *ctx);
-int agx_ctx_timer_stop(agx_ctx *ctx, float *elapsed_ms);
+int agx_ctx_timer_stop(agx_ctx *ctx, float *elapsed_ms); /* second event + wait + elapsed */
+/* The same stopwatch in two halves, for timing a launch inside a longer host-timed step without an extra
+ * wait: mark() records the second event and returns at once; elapsed() (after whatever synchronised the
+ * stream, e.g. agx_sw_batch_scores) reads the time between the two events. */
+int agx_ctx_timer_mark(agx_ctx *ctx);
+int agx_ctx_timer_elapsed(agx_ctx *ctx, float *elapsed_ms);
 
 /* ----------------------------------------------------------- Smith-Waterman */
 
