@@ -402,7 +402,7 @@ def main():
                "score_checksum": sw_sum},
         "sw_int32": dict(i32_leg, metric="config 2 through the int32 kernel (one pair per lane group, AGX_SW_KERNEL_INT32)", unit="GCUPS",
                          scores_identical_to_packed=i32_same, useful_cell_fraction=i32_info.cells / max(1, i32_info.padded_cells),
-                         roofline=roof(sw.algorithmic_bytes(), i32_t["launch_ms"], None)),
+                         roofline=roof(sw.algorithmic_bytes(), i32_t["launch_ms"], "sw_fill_int32")),
         "pairhmm": dict(ph_leg, metric="PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)", unit="pairs/s",
                         dtype="f32 (two haplotypes per lane group, packed FMA; double rescue)",
                         gcups=n_gpus * ph.cells() * ph_t["steps"] / ph_t["dt"] / 1e9, rescued_in_f64=int(ph_rescued),
