@@ -26,7 +26,7 @@ PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
 # every symbol include/agx.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
-    "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_set_option", "agx_host_alloc", "agx_host_free",
+    "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_set_option", "agx_warmup_devices", "agx_host_alloc", "agx_host_free",
     "agx_ctx_timer_start", "agx_ctx_timer_stop", "agx_ctx_timer_mark", "agx_ctx_timer_elapsed",
     "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi", "agx_sw_score_devices", "agx_sw_shard_cuts",
@@ -122,6 +122,7 @@ def lib():
         l.agx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         l.agx_ctx_sync.argtypes = [C.c_void_p]
         l.agx_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+        l.agx_warmup_devices.argtypes = [C.c_void_p, C.c_int]
         l.agx_host_alloc.argtypes = [C.c_size_t]
         l.agx_host_alloc.restype = C.c_void_p
         l.agx_host_free.argtypes = [C.c_void_p]

@@ -280,7 +280,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         }
         n_pairs = out0[ng];
         gen0.resize((size_t)fill0[ng]);
-        agx_parallel_for((int64_t)ng, 1, [&](int64_t ga, int64_t gz, int) {
+        // (grain: about 16384 pairs per part -- smaller parts cost more in hand-over than they save)
+        const int64_t region_grain = std::max<int64_t>(1, 16384 / std::max<int64_t>(1, n_pairs / std::max<uint32_t>(ng, 1)));
+        agx_parallel_for((int64_t)ng, region_grain, [&](int64_t ga, int64_t gz, int) {
             for (int64_t g = ga; g < gz; ++g) {
                 const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
                 size_t at = (size_t)fill0[(size_t)g];
@@ -369,7 +371,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         return AGX_E_ARG;
     }
     if (have_tracks) {
-        agx_parallel_for((int64_t)n_reads, 256, [&](int64_t ra, int64_t rz, int) {
+        agx_parallel_for((int64_t)n_reads, 2048, [&](int64_t ra, int64_t rz, int) {
             for (int64_t r = ra; r < rz; ++r) {
                 const uint64_t o = d->read_off[r];
                 const size_t R = (size_t)(d->read_off[r + 1] - o), trk = (R + 3) / 4;
@@ -389,7 +391,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 }
             }
         });
-        agx_parallel_for((int64_t)n_haps, 256, [&](int64_t ha, int64_t hz, int) {
+        agx_parallel_for((int64_t)n_haps, 2048, [&](int64_t ha, int64_t hz, int) {
             for (int64_t h = ha; h < hz; ++h) {
                 const uint64_t o = d->hap_off[h];
                 const size_t H = (size_t)(d->hap_off[h + 1] - o);

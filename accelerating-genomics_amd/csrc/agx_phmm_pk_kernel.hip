@@ -6,7 +6,7 @@
 //     t = gm * (X_d + Y_d)            v_pk_add_f32, v_pk_mul_f32
 //     M = prior * fma(mm, M_d, t)     v_pk_fma_f32, v_pk_mul_f32     (antidiagsPairHMM.c:184)
 //     X = fma(M_up, Qi, X_up * Qg)    v_pk_mul_f32, v_pk_fma_f32     (:189)
-//     Y = fma(M_left, Qd, Y_left*Qg)  v_pk_mul_f32, v_pk_fma_f32     (:194)
+//     Y = fma(Y_left, Qg, M_left*Qd)  v_pk_mul_f32, v_pk_fma_f32     (:194; the product is off the column chain)
 // = 8 packed instructions + 2 compares + 2 selects per 2 cells, against 11 + 2 scalar ones per cell
 // in the order-exact float kernel; v_pk_*_f32 issue at 75 T elements/s on this chip where
 // v_mul/v_add_f32 reach 65 and v_fma_f32 42 (tools/valu_microbench.hip), and
@@ -193,12 +193,15 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
                 X[j] = x;
                 M[j] = m;
             }
-            // pass B, left to right: Y needs the new M and Y of column j-1
-            f2 cM = lM, cY = lY;
+            // pass B, left to right: Y needs the new M and Y of column j-1.  The products M * Qd do not depend on
+            // the chain, so only one fused multiply-add per column sits on it (mul + fma, both on the chain, took
+            // twice the latency per column and half of the loop's hazard nops).
+            f2 cY = lY;
+            f2 a[3] = {lM * qd, M[0] * qd, C > 1 ? M[C > 1 ? 1 : 0] * qd : splat(0.f)}; // products run three columns ahead of the chain
 #pragma unroll
             for (int j = 0; j < C; ++j) {
-                const f2 y = fma2(cM, qd, cY * qg);
-                cM = M[j];
+                const f2 y = fma2(cY, qg, a[j % 3]);
+                if (j + 3 < C + 1) a[j % 3] = M[j + 2 < C ? j + 2 : C - 1] * qd;
                 cY = y;
                 Y[j] = y;
             }

@@ -539,6 +539,30 @@ int agx_ctx_timer_elapsed(agx_ctx *c, float *ms)
     return AGX_OK;
 }
 
+int agx_warmup_devices(const int *devices, int n_devices)
+{
+    AGX_GUARD_BEGIN
+    const int avail = agx_device_count();
+    if (avail <= 0) {
+        agx_set_error("no HIP device is visible (this library has no CPU fallback)");
+        return AGX_E_NODEVICE;
+    }
+    if (!devices && (n_devices <= 0 || n_devices > avail)) n_devices = avail;
+    std::vector<int> slot_of((size_t)avail, 0);
+    for (int k = 0; k < n_devices; ++k) {
+        const int dev = devices ? devices[k] : k;
+        if (dev < 0 || dev >= avail) {
+            agx_set_error("agx_warmup_devices: device %d out of range [0,%d)", dev, avail);
+            return AGX_E_NODEVICE;
+        }
+        agx_ctx *c = nullptr;
+        const int rc = agx_shared_ctx(dev, slot_of[(size_t)dev]++, &c); // shards sharing a device have contexts of their own
+        if (rc) return rc;
+    }
+    return AGX_OK;
+    AGX_GUARD_END("agx_warmup_devices")
+}
+
 void *agx_host_alloc(size_t bytes)
 {
     void *p = nullptr;

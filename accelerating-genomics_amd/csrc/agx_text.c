@@ -69,6 +69,7 @@ struct agx_sw_reader {
     char *buf;
     size_t cap, lo, hi;
     int eof;
+    size_t hint_bases, hint_pairs; /* size of the previous chunk: the next one reserves that much up front */
 };
 
 /* next line -> *p (valid until the next call), its strlen() in *n; 0 = no line left */
@@ -174,6 +175,12 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
     int rc = AGX_E_NOMEM;
     if (!t) goto done;
     t->line_num = r->line_num;
+    if (r->hint_pairs) { /* a chunk like the last one: no regrowing (and recopying) of 100+ MB buffers */
+        const size_t np = r->hint_pairs < (size_t)max_pairs ? r->hint_pairs : (size_t)max_pairs;
+        if (buf_reserve(&bases, r->hint_bases + r->hint_bases / 16 + 4096) || buf_reserve(&off, 2 * np * sizeof(uint64_t)) ||
+            buf_reserve(&len, 2 * np * sizeof(uint32_t)))
+            goto done;
+    }
     while (!r->finished && t->n_pairs < max_pairs) {
         if (r->lines_taken >= r->line_num) { /* loop condition of :216 */
             r->finished = 1;
@@ -207,6 +214,8 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
     t->bases = bases.p;
     t->off = (uint64_t *)off.p;
     t->len = (uint32_t *)len.p;
+    r->hint_bases = bases.n;
+    r->hint_pairs = (size_t)t->n_pairs;
     bases.p = off.p = len.p = NULL;
     rc = AGX_OK;
 done:

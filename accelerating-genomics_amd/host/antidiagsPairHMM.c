@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "agx.h"
 #include "agx_pipe.h"
@@ -54,6 +55,18 @@ typedef struct {
     agx_phmm_text *text;
     double *lh;
 } scored_chunk;
+
+typedef struct {
+    const int *devices; /* NULL: devices 0 .. n-1 */
+    int n;
+} warm_t;
+
+static void *warm_main(void *arg)
+{
+    warm_t *w = (warm_t *)arg;
+    (void)agx_warmup_devices(w->devices, w->n); /* HIP start-up beside the parsing; a failure shows at the first batch */
+    return NULL;
+}
 
 typedef struct {
     agx_pipe q;
@@ -121,15 +134,23 @@ int main(int argc, const char *argv[])
     ps.chunk_pairs = cp && atoll(cp) > 0 ? atoll(cp) : 65536;
     agx_pipe_init(&ps.q, 2);
     agx_pipe_init(&pr.q, 2);
-    pthread_t parser, printer;
-    if (pthread_create(&parser, NULL, parser_main, &ps) || pthread_create(&printer, NULL, printer_main, &pr)) {
+    pthread_t parser, printer, warmer;
+    warm_t warm;
+    warm.devices = n_dev ? devices : NULL;
+    warm.n = n_dev ? n_dev : n_multi;
+    if (pthread_create(&parser, NULL, parser_main, &ps) || pthread_create(&printer, NULL, printer_main, &pr) ||
+        pthread_create(&warmer, NULL, warm_main, &warm)) {
         fprintf(stderr, "antidiagsPairHMM: cannot start threads\n");
         return EXIT_FAILURE;
     }
-    int status = EXIT_SUCCESS, truncated = 0;
+    int status = EXIT_SUCCESS, truncated = 0, warm_joined = 0;
     for (;;) {
         agx_phmm_text *t = (agx_phmm_text *)agx_pipe_pop(&ps.q);
         if (!t) break;
+        if (!warm_joined) {
+            pthread_join(warmer, NULL);
+            warm_joined = 1;
+        }
         truncated |= t->truncated;
         scored_chunk *c = (scored_chunk *)calloc(1, sizeof *c);
         double *lh = (double *)malloc(sizeof(double) * (size_t)(t->n_pairs ? t->n_pairs : 1));
@@ -170,7 +191,10 @@ int main(int argc, const char *argv[])
             status = EXIT_FAILURE;
         }
     }
+    if (!warm_joined) pthread_join(warmer, NULL);
     fclose(pr.out);
     agx_phmm_reader_close(ps.reader);
-    return status;
+    /* everything is written: leave without tearing the HIP runtime down */
+    fflush(NULL);
+    _exit(status);
 }

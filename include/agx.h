@@ -81,6 +81,10 @@ int agx_ctx_sync(agx_ctx *ctx);
 #define AGX_SW_KERNEL_PACKED_SIGNED 2 /* two pairs per lane group, signed int16 halves */
 #define AGX_SW_KERNEL_PACKED_BIASED 3 /* two pairs per lane group, biased unsigned halves (the default where it fits) */
 int agx_ctx_set_option(agx_ctx *ctx, int key, int64_t value);
+/* Brings the HIP runtime and the process-wide contexts of these devices up (the ones agx_*_devices / agx_*_multi /
+ * agx_pairHMM use) without computing anything: about 0.2 s that a host can spend on another thread while it
+ * parses its input (both drop-in command lines do).  devices == NULL: devices 0 .. n_devices-1, n_devices <= 0: all. */
+int agx_warmup_devices(const int *devices, int n_devices);
 /* Page-locked host memory.  Batches built from buffers allocated here are uploaded by DMA straight from
  * the caller's memory (about twice the rate of pageable memory, and asynchronously).  Optional: every
  * entry point accepts ordinary malloc'ed buffers. */

@@ -88,6 +88,38 @@ class Oracle:
         return s[:k].copy(), l[:k].copy()
 
 
+def _threads():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def sw_batch_mt(orc, b, variant=1, threads=None):
+    """The oracle over contiguous slices of b on several host cores (ctypes releases the GIL): full-size configs
+    are checked pair by pair, not by sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = b.n_pairs
+    t = max(1, min(threads or _threads(), n // 256 or 1))
+    cuts = np.linspace(0, n, t + 1).astype(np.int64)
+    with ThreadPoolExecutor(t) as ex:
+        parts = list(ex.map(lambda k: orc.sw_batch(b.subset(np.arange(cuts[k], cuts[k + 1])), variant), range(t)))
+    return np.concatenate(parts) if parts else np.zeros(0, np.int32)
+
+
+def phmm_batch_mt(orc, b, variant=0, threads=None):
+    """Same for PairHMM, by whole regions -> (raw sums, log10 likelihoods)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    ng = b.n_regions
+    t = max(1, min(threads or _threads(), ng))
+    cuts = np.linspace(0, ng, t + 1).astype(np.int64)
+    with ThreadPoolExecutor(t) as ex:
+        parts = list(ex.map(lambda k: orc.phmm_batch(b.regions(int(cuts[k]), int(cuts[k + 1])), variant), range(t)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
 def build():
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
 

@@ -8,6 +8,7 @@ import pytest
 
 import accelerating_genomics_amd.api as agx
 import accelerating_genomics_amd.synth as synth
+from tests import oracle_api
 from tests.test_oracle_sw import expect_scores
 
 pytestmark = pytest.mark.gpu
@@ -96,13 +97,19 @@ def test_batch_object_relaunch_is_idempotent(ctx, oracle):
 
 
 def test_full_size_config2_properties(ctx, oracle):
-    """BASELINE config 2 at full size (65 536 pairs, 150x150): too big for the scalar oracle in
-    seconds, so check (a) a 2 048-pair sample against it, (b) score(a,b) == score(b,a),
-    (c) identical pairs score len+1 (the '\\n' sentinel matches too)."""
+    """BASELINE config 2 at full size (65 536 pairs, 150x150): (a) EVERY pair against the oracle (its row-major
+    restatement threaded over the host cores, about a second), (b) score(a,b) == score(b,a),
+    (c) identical pairs score len+1 (the '\\n' sentinel matches too), (d) the int32 and the
+    first packed kernel give the same 65 536 scores."""
     b = synth.sw_pairs(65536, 150, 150, seed=2, related_frac=0.25)
     got = ctx.sw_score(b)
-    idx = np.arange(0, 65536, 32)
-    assert np.array_equal(got[idx], oracle.sw_batch(b.subset(idx)))
+    assert np.array_equal(got, oracle_api.sw_batch_mt(oracle, b))
+    for kern in (agx.SW_KERNEL_INT32, agx.SW_KERNEL_PACKED_SIGNED):
+        ctx.set_option(agx.OPT_SW_KERNEL, kern)
+        try:
+            assert np.array_equal(ctx.sw_score(b), got), kern
+        finally:
+            ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_AUTO)
     swapped = synth.SWBatch(b.bases, b.off.reshape(-1, 2)[:, ::-1].reshape(-1).copy(), b.len.reshape(-1, 2)[:, ::-1].reshape(-1).copy())
     assert np.array_equal(ctx.sw_score(swapped), got)
     same = synth.SWBatch(b.bases, np.repeat(b.off[0::2], 2), np.repeat(b.len[0::2], 2))
@@ -111,13 +118,13 @@ def test_full_size_config2_properties(ctx, oracle):
 
 def test_full_size_config4_mixed_lengths(ctx, oracle):
     """BASELINE config 4 at full size (1 048 576 pairs, both lengths U[32,512]); one GPU takes the
-    whole batch here (the 8-GPU run shards it).  (a) a 1/256 sample (4 096 pairs) against the
-    oracle, (b) scoring two halves separately == scoring the whole, (c) score(a,b) == score(b,a)
+    whole batch here (the 8-GPU run shards it).  (a) a 1/16 sample (65 536 pairs, every 16th) against the
+    threaded oracle, (b) scoring two halves separately == scoring the whole, (c) score(a,b) == score(b,a)
     on a 64k slice."""
     b = synth.sw_pairs(1 << 20, 32, 512, seed=4)
     got = ctx.sw_score(b)
-    idx = np.arange(0, 1 << 20, 256)
-    assert np.array_equal(got[idx], oracle.sw_batch(b.subset(idx)))
+    idx = np.arange(0, 1 << 20, 16)
+    assert np.array_equal(got[idx], oracle_api.sw_batch_mt(oracle, b.subset(idx)))
     half = 1 << 19
     lo = synth.SWBatch(b.bases, b.off[: 2 * half], b.len[: 2 * half])
     hi = synth.SWBatch(b.bases, b.off[2 * half :], b.len[2 * half :])
