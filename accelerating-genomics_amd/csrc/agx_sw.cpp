@@ -55,12 +55,12 @@ int force_cols_per_lane()
     }();
     return v;
 }
-int max_classes()
+int max_classes_override() // 0 = none
 {
     static const int v = [] {
         const char *e = agx_tune("AGX_SW_MAX_CLASSES");
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? n : 6;
+        return n > 0 ? n : 0;
     }();
     return v;
 }
@@ -751,7 +751,14 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             const char *e = agx_tune("AGX_SW_WAVES_PER_CLASS");
             return e && atof(e) > 0 ? atof(e) : 4096.0;
         }();
-        const int k_max = std::min(max_classes(), 1 + (int)(waves_est / per_class));
+        // The biased packed kernel runs every class in ONE launch (sw_fill_pk2_any), so from about two wavefronts
+        // per SIMD on it keeps them all: padding shrinks (useful cells 0.908 -> 0.932 on config 4's per-GPU shard)
+        // and nothing is forked or joined: 131 072 mixed pairs 5.62 -> 6.02 TCUPS, 262 144 6.05 -> 6.39, 65 536
+        // 5.48 -> 5.81.  Smaller batches are in the tail regime, where the launch lasts as long as its longest
+        // waves and the few-classes rule still wins (16 384 pairs: 3.58 against 3.02 TCUPS; tools/sw_mixed_check.py).
+        const int k_max = max_classes_override()                  ? std::min(max_classes_override(), 1 + (int)(waves_est / per_class))
+                          : family == 2 && waves_est >= 2048.0 ? kSwNumClasses
+                                                                  : std::min(6, 1 + (int)(waves_est / per_class));
         int used = 0;
         for (int c = 0; c < kSwNumClasses; ++c) used += work[c] > 0;
         if (used > k_max) {
@@ -867,6 +874,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             w.n_groups = (uint16_t)std::min(per_wave, q.n_groups - wl * per_wave);
             w.G = (uint16_t)q.G;
             w.steps = plan[q.first + wl * per_wave * slots].ly + (uint32_t)q.G - 1u; // rows are sorted long first
+            w.reserved = (uint32_t)kSwClasses[q.cls];
             waves[q.wave0 + wl] = w;
             padded += (int64_t)w.steps * 64 * kSwClasses[q.cls] * slots;
         }
@@ -877,7 +885,23 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         const char *e = agx_tune("AGX_SW_SORT_WAVES");
         return !(e && e[0] == '0');
     }();
-    if (sort_waves && !launches.empty())
+    // A mixed batch of the biased packed kernel is ONE launch (sw_fill_pk2_any): all its waves in one list,
+    // longest first across the classes.
+    static const bool one_launch_ok = [] {
+        const char *e = agx_tune("AGX_SW_ONE_LAUNCH");
+        return !(e && e[0] == '0');
+    }();
+    if (family == 2 && launches.size() > 1 && one_launch_ok) {
+        if (sort_waves)
+            std::stable_sort(waves.begin(), waves.end(), [](const SwWave &a, const SwWave &b) {
+                return (uint64_t)a.steps * a.reserved > (uint64_t)b.steps * b.reserved;
+            });
+        ClassLaunch all_classes;
+        all_classes.C = 0; // 0 = every class, read per wave
+        all_classes.first_wave = 0;
+        all_classes.n_waves = (uint32_t)waves.size();
+        launches.assign(1, all_classes);
+    } else if (sort_waves && !launches.empty())
         agx_pool_run((int)launches.size(), [&](int k) {
             const ClassLaunch &cl = launches[(size_t)k];
             std::stable_sort(waves.begin() + cl.first_wave, waves.begin() + cl.first_wave + cl.n_waves,
@@ -1061,6 +1085,8 @@ int agx_sw_batch_launch(agx_sw_batch *b)
         if (b->matrix)
             r = agx_sw_mat_launch_class(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
                                         (const int16_t *)b->table.p, st);
+        else if (b->family == 2 && cl.C == 0)
+            r = agx_sw_pk2_launch_any(b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 2)
             r = agx_sw_pk2_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 1)

@@ -47,7 +47,7 @@ struct SwWave {
     uint16_t n_groups;
     uint16_t G;
     uint32_t steps;
-    uint32_t reserved;
+    uint32_t reserved; // columns per lane of this wave's class (read by the one-launch kernel of mixed batches)
 };
 
 // Column-per-lane classes the kernels are instantiated for (any width works: a lane's symbols are
@@ -83,6 +83,9 @@ int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
+// every class of a mixed batch in one launch: waves[].reserved holds each wave's columns per lane
+int agx_sw_pk2_launch_any(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+                          int32_t *scores, hipStream_t s);
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_wide_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,

@@ -60,22 +60,17 @@ __device__ __forceinline__ uint32_t shr1u(uint32_t old, uint32_t v)
 }
 
 template <int C>
-__global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uint32_t *__restrict__ img,
-                                                   const SwGroup2 *__restrict__ groups,
-                                                   const SwWave *__restrict__ waves, uint32_t n_waves,
-                                                   int32_t *__restrict__ scores)
+__device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
+                                         const SwWave w, int32_t *__restrict__ scores)
 {
     static_assert(C % 2 == 0, "the running maximum takes two columns per instruction");
     constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
     const int sh_sym = prm.shift;              // symbols live as byte << shift
     const uint32_t row_pad = 0x100u << sh_sym; // never equals (byte << shift)
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (wave >= n_waves) return;
     const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(prm.agf2), hd = in_vgpr(prm.hd2); // |ge|, |gf|, match + |gf|
     const uint32_t bias = prm.bias2, delta = prm.delta2;
     const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf)
     const int lane = threadIdx.x & 63;
-    const SwWave w = waves[wave];
     const int G = w.G;
     const int grp = lane / G;
     const int gl = lane - grp * G;
@@ -206,6 +201,39 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 }
 
 template <int C>
+__global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uint32_t *__restrict__ img,
+                                                   const SwGroup2 *__restrict__ groups,
+                                                   const SwWave *__restrict__ waves, uint32_t n_waves,
+                                                   int32_t *__restrict__ scores)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wave >= n_waves) return;
+    pk2_body<C>(prm, img, groups, waves[wave], scores);
+}
+
+// Mixed batches: ONE launch for every lane-tiling class.  Each wavefront reads its class (columns per lane)
+// from its record and runs that class's fill; the kernel is allocated the registers of the widest class
+// (100 VGPRs, five waves per SIMD -- the fill is bound by VALU issue, not by occupancy).  Against one launch
+// per class this (a) lets the planner use every width, so padding shrinks, (b) dispatches the waves of ALL
+// classes longest first, (c) has no stream fork/join and no per-launch ramp.
+__global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const uint32_t *__restrict__ img,
+                                                       const SwGroup2 *__restrict__ groups,
+                                                       const SwWave *__restrict__ waves, uint32_t n_waves,
+                                                       int32_t *__restrict__ scores)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (wave >= n_waves) return;
+    const SwWave w = waves[wave];
+    switch (__builtin_amdgcn_readfirstlane(w.reserved)) { // columns per lane of this wave
+#define AGX_SW_CASE(CC) \
+    case CC: pk2_body<CC>(prm, img, groups, w, scores); break;
+        AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
+#undef AGX_SW_CASE
+    default: break;
+    }
+}
+
+template <int C>
 int launch(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
            int32_t *scores, hipStream_t s)
 {
@@ -215,6 +243,15 @@ int launch(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, con
 }
 
 } // namespace
+
+int agx_sw_pk2_launch_any(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+                          int32_t *scores, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    const uint32_t blocks = (n_waves + 3) / 4;
+    hipLaunchKernelGGL(sw_fill_pk2_any, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s)
