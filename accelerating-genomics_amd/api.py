@@ -331,10 +331,13 @@ class PhmmBatchDev:
     def launch(self):
         _check(lib().agx_phmm_batch_launch(self._h))
 
-    def results(self, out=None):
-        """-> (log10 likelihoods, raw sums), float64; out = (l, s) arrays to reuse."""
-        l, s = out if out is not None else (np.empty(self.n_pairs, np.float64), np.empty(self.n_pairs, np.float64))
-        _check(lib().agx_phmm_batch_results(self._h, _ptr(l), _ptr(s)))
+    def results(self, out=None, want_sums=True):
+        """-> (log10 likelihoods, raw sums), float64; out = (l, s) arrays to reuse; want_sums=False fetches the
+        likelihoods only (raw_sum = NULL in the C call) and returns (l, None)."""
+        l, s = out if out is not None else (np.empty(self.n_pairs, np.float64), np.empty(self.n_pairs, np.float64) if want_sums else None)
+        if not want_sums:
+            s = None
+        _check(lib().agx_phmm_batch_results(self._h, _ptr(l), _ptr(s) if s is not None else None))
         return l, s
 
     def info(self) -> PhmmInfo:

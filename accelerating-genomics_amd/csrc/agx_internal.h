@@ -131,6 +131,18 @@ static inline int agx_bind(const agx_ctx *c)
     return AGX_OK;
 }
 
+// true when p is page-locked host memory the device can DMA into or out of directly (agx_host_alloc,
+// hipHostMalloc, hipHostRegister); an ordinary malloc'ed pointer is "invalid" to the runtime, which is not an error here
+static inline bool agx_is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
 // Process-wide contexts for the entry points that take device ordinals instead of a context
 // (agx_*_devices, agx_*_multi, agx_pairHMM): created on first use, kept until the process ends.
 // slot distinguishes several shards mapped onto the same device.

@@ -191,7 +191,7 @@ struct agx_phmm_batch {
     int64_t n_pairs = 0;
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
-    DevBuf img, sums, lut, counter;
+    DevBuf img, sums, logs, lut, counter; // logs: float modes only (log10 taken on the device)
     struct DevPlan {
         DevBuf groups, tabs, waves;
         std::vector<ClassLaunch> launches;
@@ -424,7 +424,11 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         // haplotypes by length and tile neighbours for the longer of the two, so that partners get the
         // same class (mixed-length regions would otherwise leave most second slots vacant).
         for (Plan &p : gen) p.th = p.H;
-        if (slots == 2) {
+        // (fixed-length input -- BASELINE configs 3 and 5 -- needs neither this pairing nor the sorts below: every
+        // key is equal, the enumeration order already is the order they would produce)
+        bool one_shape = !gen.empty();
+        for (size_t k = 1; k < gen.size() && one_shape; ++k) one_shape = gen[k].R == gen[0].R && gen[k].H == gen[0].H;
+        if (slots == 2 && !one_shape) {
             size_t a = 0;
             while (a < gen.size()) {
                 size_t z = a;
@@ -534,7 +538,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
         // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
         std::vector<Plan> plan;
-        {
+        if (one_shape)
+            plan.swap(gen); // one (R, H) shape: one class, one G, equal keys throughout
+        else {
             uint32_t max_r = 0;
             for (const Plan &p : gen) max_r = std::max(max_r, p.R);
             std::vector<Plan> tmp;
@@ -762,6 +768,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (!rc && !pstripe.waves.empty()) rc = b->stripe_scratch.alloc(ctx, (size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
     if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
+    if (!rc && two_pass) rc = b->logs.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double));
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
@@ -809,6 +816,7 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
         pl->waves.release();
     }
     b->sums.release();
+    b->logs.release();
     b->lut.release();
     b->counter.release();
     agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
@@ -926,43 +934,54 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
-    // through pinned staging on the launch stream: the DMA queues right behind the last kernel
+    // through pinned staging on the launch stream: the DMAs queue right behind the last kernel
     const size_t sum_bytes = (size_t)b->n_pairs * sizeof(double);
+    const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
+    // antidiagsPairHMM.c:242 -- both logarithms in double: by the host libm for the double modes (bit-identical to
+    // the reference's output), by the device for the float modes (agx_phmm_finish_kernel.hip)
+    const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
+    const bool want_sums = raw_sum != nullptr || !f32;
     PinBuf stage;
-    rc = stage.alloc(b->ctx, sum_bytes + sizeof(unsigned long long));
+    rc = stage.alloc(b->ctx, (want_sums ? sum_bytes : 0) + (f32 ? sum_bytes : 0) + sizeof(unsigned long long));
     if (rc) return rc;
     struct StageGuard {
         PinBuf &s;
         ~StageGuard() { s.release(); }
     } stage_guard{stage};
-    if (b->n_pairs) AGX_HIP(hipMemcpyAsync(stage.p, b->sums.p, sum_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
-    AGX_HIP(hipMemcpyAsync((char *)stage.p + sum_bytes, b->counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->ctx->stream));
-    AGX_HIP(hipStreamSynchronize(b->ctx->stream));
-    unsigned long long nres = 0;
-    memcpy(&nres, (char *)stage.p + sum_bytes, sizeof nres);
-    b->info.n_rescued = (int64_t)nres;
-    double *s = (double *)stage.p; // sign fix-ups of the float modes happen in place, then raw_sum (if wanted) gets a copy
-    // antidiagsPairHMM.c:242 -- both logarithms by the host libm, in double
-    const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
-    const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
-    agx_parallel_for(b->n_pairs, 2048, [&](int64_t lo, int64_t hi, int) {
-        for (int64_t k = lo; k < hi; ++k) {
-            double v = s[k];
-            if (f32) {
-                // the rescue pass stores its double-scaled sum negated so the two scalings stay apart
-                if (std::signbit(v) && v != 0) {
-                    v = -v;
-                    log10_lik[k] = log10(v) - c64;
-                } else {
-                    log10_lik[k] = log10(v) - c32;
-                }
-                s[k] = v;
-            } else {
-                log10_lik[k] = log10(v) - c64;
-            }
+    char *at = (char *)stage.p;
+    double *s = nullptr, *dev_logs = nullptr;
+    hipStream_t st = b->ctx->stream;
+    if (f32 && b->n_pairs) {
+        if (agx_phmm_finish_launch((const double *)b->sums.p, (double *)b->logs.p, (uint32_t)b->n_pairs, c64, c32, st)) {
+            agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return AGX_E_HIP;
         }
-    });
-    if (raw_sum && b->n_pairs) memcpy(raw_sum, s, sum_bytes);
+        dev_logs = agx_is_pinned_host(log10_lik) ? log10_lik : (double *)at; // page-locked destination: no staging copy
+        AGX_HIP(hipMemcpyAsync(dev_logs, b->logs.p, sum_bytes, hipMemcpyDeviceToHost, st));
+        at += sum_bytes;
+    }
+    if (want_sums) {
+        s = (double *)at;
+        if (b->n_pairs) AGX_HIP(hipMemcpyAsync(s, b->sums.p, sum_bytes, hipMemcpyDeviceToHost, st));
+        at += sum_bytes;
+    }
+    AGX_HIP(hipMemcpyAsync(at, b->counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    AGX_HIP(hipStreamSynchronize(st));
+    unsigned long long nres = 0;
+    memcpy(&nres, at, sizeof nres);
+    b->info.n_rescued = (int64_t)nres;
+    if (f32) {
+        if (b->n_pairs && dev_logs != log10_lik) memcpy(log10_lik, dev_logs, sum_bytes);
+    } else
+        agx_parallel_for(b->n_pairs, 2048, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t k = lo; k < hi; ++k) log10_lik[k] = log10(s[k]) - c64;
+        });
+    if (raw_sum && b->n_pairs) {
+        if (f32) // the rescue pass stores its double-scaled sum negated so the two scalings stay apart: callers get |sum|
+            for (int64_t k = 0; k < b->n_pairs; ++k) raw_sum[k] = s[k] < 0 ? -s[k] : s[k];
+        else
+            memcpy(raw_sum, s, sum_bytes);
+    }
     return AGX_OK;
     AGX_GUARD_END("agx_phmm_batch_results")
 }

@@ -1,0 +1,34 @@
+// The last line of pairHMM() -- log10(sum) - log10(C), antidiagsPairHMM.c:242 -- for the FLOAT modes, on the device.
+//
+// The double modes keep it on the host: their results are compared bit for bit with the reference's "%.17g"
+// output, and only the host libm rounds like the reference's.  The float modes promise 1e-6 relative; a double
+// log10 on the device is good to an ulp of double, and it takes 0.1 ms of host time per 65 536 pairs out of the
+// launch -> results-on-host window (bench.py's pairhmm leg: 0.55 -> 0.45 ms per step).
+// Pairs the rescue pass (or the striped kernel) recomputed in double arrive with their sum negated: they are
+// scaled by DBL_MAX/16, the others by FLT_MAX/16.  sums[] itself is left alone (results may be fetched twice).
+#include "agx_phmm.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) phmm_finish_f32(const double *__restrict__ sums, double *__restrict__ logs, uint32_t n,
+                                                       double log_c64, double log_c32)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    double v = sums[k];
+    double c = log_c32;
+    if (v < 0.0) { // (-0.0 is not below zero: an all-zero sum stays a float-scaled zero, log10 -> -inf either way)
+        v = -v;
+        c = log_c64;
+    }
+    logs[k] = log10(v) - c;
+}
+
+} // namespace
+
+int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32, hipStream_t s)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(phmm_finish_f32, dim3((n + 255) / 256), dim3(256), 0, s, sums, logs, n, log_c64, log_c32);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

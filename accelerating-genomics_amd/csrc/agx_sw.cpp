@@ -1118,9 +1118,15 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
         AGX_HIP(hipStreamSynchronize(b->ctx->stream));
         return AGX_OK;
     }
-    // through pinned staging on the launch stream: one DMA right behind the last kernel, then a host copy
-    // (a pageable destination makes the runtime stage the copy itself, later and slower)
+    // one DMA right behind the last kernel on the launch stream: straight into the caller's array when that is
+    // page-locked (agx_host_alloc), else through pinned staging and a host copy (a pageable destination would
+    // make the runtime stage the copy itself, later and slower)
     const size_t bytes = (size_t)b->n_pairs * sizeof(int32_t);
+    if (agx_is_pinned_host(scores)) {
+        AGX_HIP(hipMemcpyAsync(scores, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+        return AGX_OK;
+    }
     PinBuf stage;
     rc = stage.alloc(b->ctx, bytes);
     if (rc) return rc;

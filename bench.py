@@ -61,7 +61,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # v_pk_* instruction 4.2 cycles per SIMD; v_add/sub/xor_u32 2.4 in a pure stream but 4.2 beside packed ones
 # (profiles/r02_valu_microbench3.log), so every instruction of the cell is priced at the packed rate.
 VALU_PACKED, VALU_SLOW = 37.5e12, 38e12  # lane-instructions / s
-WINDOW = "kernel launch -> results resident in host memory, inputs resident in HBM (hipvers.cpp:475-483)"
+WINDOW = "kernel launch -> results resident in (page-locked) host memory, inputs resident in HBM (hipvers.cpp:475-483)"
 
 
 # ----------------------------------------------------------------------------------------- CPU baselines
@@ -259,7 +259,7 @@ def main():
 
     # ---------------- Smith-Waterman, BASELINE config 2 (per rank: its own seed => its own shard)
     sw = synth.sw_pairs(SW_PAIRS, SW_LEN, SW_LEN, seed=2 + 1000 * rank, related_frac=0.25)
-    sw_out = np.empty(sw.n_pairs, np.int32)
+    sw_out = agx.host_array(sw.n_pairs, np.int32)  # results land in page-locked host memory: one DMA, no staging copy
     sw_dev = ctx.sw_batch(sw)
     sw_info = sw_dev.info()
     sw_t = timed(sw_dev, lambda: sw_dev.scores(sw_out), args.steps, args.warmup)
@@ -271,17 +271,17 @@ def main():
     i32_dev = ctx.sw_batch(sw)
     ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_AUTO)
     i32_info = i32_dev.info()
-    i32_out = np.empty(sw.n_pairs, np.int32)
+    i32_out = agx.host_array(sw.n_pairs, np.int32)
     i32_t = timed(i32_dev, lambda: i32_dev.scores(i32_out), *few())
     i32_same = bool(np.array_equal(i32_out, sw_out))
     i32_dev.close()
 
     # ---------------- PairHMM, BASELINE config 3
     ph = synth.phmm_regions(PH_REGIONS, PH_READS, PH_HAPS, PH_R, PH_H, seed=3 + 1000 * rank)
-    ph_out = (np.empty(ph.n_pairs), np.empty(ph.n_pairs))
+    ph_out = (agx.host_array(ph.n_pairs, np.float64), None)
     ph_dev = ctx.phmm_batch(ph, agx.PHMM_F32_FMA)
     ph_info = ph_dev.info()
-    ph_t = timed(ph_dev, lambda: ph_dev.results(ph_out), args.steps, args.warmup)
+    ph_t = timed(ph_dev, lambda: ph_dev.results(ph_out, want_sums=False), args.steps, args.warmup)
     ph_rescued = ph_dev.info().n_rescued
     ph_sum = float(ph_out[0].sum())
     ph_dev.close()
@@ -290,17 +290,17 @@ def main():
     if extra:
         # ---------------- weak legs of the two 8-GPU configs: every rank its own 1/8-size shard
         c4 = synth.sw_pairs(C4_PAIRS // 8, 32, 512, seed=4 + 1000 * rank)
-        c4_out = np.empty(c4.n_pairs, np.int32)
+        c4_out = agx.host_array(c4.n_pairs, np.int32)
         c4_dev = ctx.sw_batch(c4)
         c4_info = c4_dev.info()
         c4_t = timed(c4_dev, lambda: c4_dev.scores(c4_out), *few())
         c4_sum = int(c4_out.astype(np.int64).sum())
         c4_dev.close()
         c5 = synth.phmm_regions(C5_REGIONS // 8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5 + 1000 * rank)
-        c5_out = (np.empty(c5.n_pairs), np.empty(c5.n_pairs))
+        c5_out = (agx.host_array(c5.n_pairs, np.float64), None)
         c5_dev = ctx.phmm_batch(c5, agx.PHMM_F64)
         c5_info = c5_dev.info()
-        c5_t = timed(c5_dev, lambda: c5_dev.results(c5_out), *few())
+        c5_t = timed(c5_dev, lambda: c5_dev.results(c5_out, want_sums=False), *few())
         c5_sum = float(c5_out[0].sum())
         c5_dev.close()
 
@@ -318,7 +318,7 @@ def main():
         c4f = synth.sw_pairs(C4_PAIRS, 32, 512, seed=4)
         cut4 = agx.sw_shard_cuts(c4f, world)
         mine4 = c4f.subset(np.arange(cut4[rank], cut4[rank + 1]))
-        s4_out = np.empty(mine4.n_pairs, np.int32)
+        s4_out = agx.host_array(mine4.n_pairs, np.int32)
         s4_dev = ctx.sw_batch(mine4)
         s4_info = s4_dev.info()
         s4_t = timed(s4_dev, lambda: s4_dev.scores(s4_out), *few())
@@ -327,9 +327,9 @@ def main():
         c5f = synth.phmm_regions(C5_REGIONS, C5_READS, C5_HAPS, C5_R, C5_H, seed=5)
         cut5 = agx.phmm_shard_cuts(c5f, world)
         mine5 = c5f.regions(int(cut5[rank]), int(cut5[rank + 1]))
-        s5_out = (np.empty(mine5.n_pairs), np.empty(mine5.n_pairs))
+        s5_out = (agx.host_array(mine5.n_pairs, np.float64), None)
         s5_dev = ctx.phmm_batch(mine5, agx.PHMM_F64)
-        s5_t = timed(s5_dev, lambda: s5_dev.results(s5_out), *few())
+        s5_t = timed(s5_dev, lambda: s5_dev.results(s5_out, want_sums=False), *few())
         s5_dev.close()
         s5_rows = per_rank_table(mine5.n_pairs, mine5.cells(), s5_t)
         # ... and through ONE process driving all the devices (agx_*_multi): rank 0 alone, the others wait on the CPU
