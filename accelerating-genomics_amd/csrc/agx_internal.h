@@ -87,6 +87,7 @@ struct agx_ctx {
     int opt_sw_kernel = 0;
 };
 
+int agx_ctx_prepare_fanout(agx_ctx *c); // side streams + events for batches of several launches
 void agx_ctx_retain(agx_ctx *c);
 void agx_ctx_release(agx_ctx *c); // frees everything when the last reference goes
 
@@ -131,19 +132,15 @@ static inline int agx_bind(const agx_ctx *c)
     return AGX_OK;
 }
 
-// true when p is page-locked host memory the device can DMA into or out of directly (agx_host_alloc,
-// hipHostMalloc, hipHostRegister); an ordinary malloc'ed pointer is "invalid" to the runtime, which is not an error here
-static inline bool agx_is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t attr;
-    if (!p || hipPointerGetAttributes(&attr, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return attr.type == hipMemoryTypeHost;
-}
+// true when [p, p + bytes) lies in a block handed out by agx_host_alloc (page-locked: the device can DMA into or
+// out of it directly).  A registry of our own rather than hipPointerGetAttributes: asked about an ordinary
+// malloc'ed pointer, the runtime's first answer in a process took 7.5 ms (tools/first_call_costs.py) -- inside
+// the launch -> scores window of a fresh process.  Memory pinned by other means is treated as pageable (staged).
+bool agx_is_pinned_host(const void *p, size_t bytes);
 
 // Process-wide contexts for the entry points that take device ordinals instead of a context
 // (agx_*_devices, agx_*_multi, agx_pairHMM): created on first use, kept until the process ends.
 // slot distinguishes several shards mapped onto the same device.
-int agx_shared_ctx(int device, int slot, agx_ctx **out);
+// *busy (may be NULL) receives the context's own mutex: a shard holds it while it uses the context, so that two
+// host threads calling agx_*_devices at once take turns per (device, slot) instead of interleaving on its streams.
+int agx_shared_ctx(int device, int slot, agx_ctx **out, std::mutex **busy = nullptr);

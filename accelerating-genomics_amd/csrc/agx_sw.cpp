@@ -241,6 +241,8 @@ struct agx_sw_batch {
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
     DevBuf table; // substitution-matrix mode: kSwMatDim^2 int16 entries
+    PinBuf out_stage; // page-locked landing block of the scores, taken at create: agx_sw_batch_scores allocates nothing
+                      // (a first hipHostMalloc costs milliseconds, and hipvers' timed window is launch -> scores)
     bool matrix = false;
     std::vector<ClassLaunch> launches;
     agx_sw_info info{};
@@ -262,6 +264,7 @@ void agx_sw_batch_destroy(agx_sw_batch *b)
     b->waves.release();
     b->scores.release();
     b->table.release();
+    b->out_stage.release();
     agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
     delete b;
 }
@@ -579,15 +582,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             // blocks, each slice's DMA runs while the next is being copied.  Pinned sources go down in one DMA.
             constexpr size_t kSlice = (size_t)16 << 20;
             constexpr int kRing = 3;
-            bool pageable = false;
-            if (raw_bytes > 2 * kSlice && !dense_copy) {
-                hipPointerAttribute_t attr;
-                if (hipPointerGetAttributes(&attr, src) != hipSuccess) {
-                    (void)hipGetLastError(); // an ordinary malloc'ed pointer is "invalid" to the runtime: not an error here
-                    pageable = true;
-                } else
-                    pageable = attr.type == hipMemoryTypeUnregistered;
-            }
+            // (known page-locked = allocated by agx_host_alloc; anything else is treated as pageable)
+            const bool pageable = raw_bytes > 2 * kSlice && !dense_copy && !agx_is_pinned_host(src, (size_t)raw_bytes);
             if (pageable) {
                 PinBuf ring[kRing];
                 hipEvent_t done[kRing] = {nullptr, nullptr, nullptr};
@@ -1009,6 +1005,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (!rc) rc = b->waves.alloc(ctx, waves_bytes);
     if (!rc && matrix) rc = b->table.alloc(ctx, table.size() * sizeof(int16_t));
     if (!rc) rc = b->scores.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of vacant packed halves
+    if (!rc) rc = b->out_stage.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(int32_t));
+    if (!rc && launches.size() > 1) rc = agx_ctx_prepare_fanout(ctx);
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
@@ -1122,18 +1120,14 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
     // page-locked (agx_host_alloc), else through pinned staging and a host copy (a pageable destination would
     // make the runtime stage the copy itself, later and slower)
     const size_t bytes = (size_t)b->n_pairs * sizeof(int32_t);
-    if (agx_is_pinned_host(scores)) {
+    if (agx_is_pinned_host(scores, bytes)) {
         AGX_HIP(hipMemcpyAsync(scores, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
         AGX_HIP(hipStreamSynchronize(b->ctx->stream));
         return AGX_OK;
     }
-    PinBuf stage;
-    rc = stage.alloc(b->ctx, bytes);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(stage.p, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream);
+    hipError_t e = hipMemcpyAsync(b->out_stage.p, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
-    if (e == hipSuccess) memcpy(scores, stage.p, bytes);
-    stage.release();
+    if (e == hipSuccess) memcpy(scores, b->out_stage.p, bytes);
     if (e != hipSuccess) {
         agx_set_error("agx_sw_batch_scores: %s", hipGetErrorString(e));
         return AGX_E_HIP;
@@ -1215,8 +1209,12 @@ int agx_sw_score_devices(const int *devices, int n_devices, const uint8_t *bases
         int r;
         try {
             agx_ctx *c = nullptr;
-            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c); // created once per process: pools stay warm
-            if (!r) r = agx_sw_score(c, bases, off + 2 * lo, len + 2 * lo, hi - lo, scores + lo);
+            std::mutex *busy = nullptr;
+            r = agx_shared_ctx(devices[k], slot[(size_t)k], &c, &busy); // created once per process: pools stay warm
+            if (!r) {
+                std::lock_guard<std::mutex> turn(*busy); // concurrent callers take turns on this (device, slot)
+                r = agx_sw_score(c, bases, off + 2 * lo, len + 2 * lo, hi - lo, scores + lo);
+            }
         } catch (const std::exception &ex) {
             agx_set_error("shard %d: %s", k, ex.what());
             r = AGX_E_NOMEM;

@@ -173,7 +173,8 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
 int agx_sw_score_multi(int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
                        int64_t n_pairs, int32_t *scores);
 /* Same with an explicit device list: shard k runs on devices[k].  An ordinal may appear several times
- * (several shards then share that GPU, each with its own context and stream). */
+ * (several shards then share that GPU, each with its own context and stream).  Callable from several host
+ * threads at once: calls take turns on each (device, shard slot) context. */
 int agx_sw_score_devices(const int *devices, int n_devices, const uint8_t *bases, const uint64_t *off, const uint32_t *len,
                          int64_t n_pairs, int32_t *scores);
 /* The cut rule of the two calls above, on the host alone: cut[0..n_shards] with shard k = pairs
