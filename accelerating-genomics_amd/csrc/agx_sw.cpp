@@ -1021,9 +1021,17 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     flag[0] = 0;
     flag[1] = 0xffffffffu;
     if (e == hipSuccess && n_groups) {
-        if (agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base, b->groups.p,
-                               (uint32_t)n_groups, (uint32_t)n_pairs, (uint32_t *)b->img.p, (const uint8_t *)d_code.p,
-                               (uint32_t *)d_flag.p, n_cu, cs)) {
+        const char *dna_knob = agx_tune("AGX_SW_DNA");
+        // the DNA-coded cell adds (mismatch + |gf|) and a table byte: both must be non-negative bytes
+        const bool dna = family == 2 && prm.delta < 128 && prm.hd >= prm.delta && !(dna_knob && dna_knob[0] == '0');
+        const int pr = dna // the biased packed fill has a DNA-coded cell: its pack kernel decides per wavefront
+                           ? agx_sw_pack_dna_launch((const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base, b->groups.p, b->waves.p,
+                                                    (uint32_t)waves.size(), (uint32_t)n_pairs, (uint32_t *)b->img.p, (uint32_t *)d_flag.p,
+                                                    n_cu, cs)
+                           : agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base,
+                                                b->groups.p, (uint32_t)n_groups, (uint32_t)n_pairs, (uint32_t *)b->img.p,
+                                                (const uint8_t *)d_code.p, (uint32_t *)d_flag.p, n_cu, cs);
+        if (pr) {
             agx_set_error("sw_pack launch failed: %s", hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }

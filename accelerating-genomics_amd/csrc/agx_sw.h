@@ -47,7 +47,8 @@ struct SwWave {
     uint16_t n_groups;
     uint16_t G;
     uint32_t steps;
-    uint32_t reserved; // columns per lane of this wave's class (read by the one-launch kernel of mixed batches)
+    uint32_t reserved; // class word: bits 0..15 columns per lane of this wave's class (read by the one-launch kernel of
+                       // mixed batches); bit 16 set on the device by sw_pack_dna: every pair of the wave is DNA-coded
 };
 
 // Column-per-lane classes the kernels are instantiated for (any width works: a lane's symbols are
@@ -79,6 +80,10 @@ int agx_sw_mat_launch_class(int cols_per_lane, const SwParams &prm, const uint32
 int agx_sw_pack_launch(bool matrix, int slots, const uint8_t *raw, const uint64_t *off, uint64_t base, const void *groups,
                        uint32_t n_groups, uint32_t n_pairs, uint32_t *img, const uint8_t *code, uint32_t *flag, int n_cu,
                        hipStream_t s);
+// The biased packed fill's variant: one pack wavefront per fill wavefront, DNA-codes the waves whose pairs all qualify
+// (rewrites their group records' lengths and sets bit 16 of the wave records' class word).
+int agx_sw_pack_dna_launch(const uint8_t *raw, const uint64_t *off, uint64_t base, void *groups, void *waves, uint32_t n_waves,
+                           uint32_t n_pairs, uint32_t *img, uint32_t *flag, int n_cu, hipStream_t s);
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,

@@ -76,7 +76,158 @@ __global__ void __launch_bounds__(256) sw_pack(const uint8_t *__restrict__ raw, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same for the biased packed fill (agx_sw_pk2_kernel.hip), plus its DNA test.  One pack wavefront per FILL
+// wavefront: it looks at every pair of that wave and, when all of them qualify, writes CODES instead of bytes
+// (and says so in bit 16 of the wave record's class word):
+//   * a pair qualifies when its shorter sequence x -- without a final newline -- holds at most four distinct
+//     symbols, and a final newline of either sequence could align with nothing but the other's final newline
+//     (no newline inside the other sequence);
+//   * x becomes v_perm_b32 selector bytes: code 0..3 (its symbols in ascending byte order; 4 + code in the group's
+//     second pair), RIGHT-aligned in the group's G * C columns, 0x0c in the padding columns before it;
+//   * y becomes shift counts 8 * (3 - code), or 31 for a symbol x does not contain and for the padding of the last
+//     quad (pk2_fill's fast_head turns them into the row tables);
+//   * final newlines are stripped and the record's lengths rewritten (lx' | both-had-one << 13 |
+//     second-is-shorter << 15 | ly' << 16) -- the fill adds the sentinel match back (see pk2_fill).
+// A wave with a pair that does not qualify (an N in a read, protein letters, ...) keeps the byte image and runs
+// the general cell.
+__device__ __forceinline__ uint32_t dna_code(uint32_t b, uint32_t syms, int nsym)
+{
+    uint32_t c = 4;
+#pragma unroll
+    for (int k = 3; k >= 0; --k)
+        if (k < nsym && b == ((syms >> (8 * k)) & 0xffu)) c = (uint32_t)k;
+    return c;
+}
+
+__global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ off, uint64_t base,
+                                                   uint32_t *__restrict__ groups, uint32_t *__restrict__ waves, uint32_t n_fill_waves,
+                                                   uint32_t n_pairs, uint32_t *__restrict__ img, uint32_t *__restrict__ flag)
+{
+    // per pack wavefront and slot (a fill wave has at most 64 groups x 2 pairs): {symbols of x, packed}, {flags, lx', ly'}
+    __shared__ uint32_t s_syms[4][128];
+    __shared__ uint32_t s_info[4][128];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    volatile uint32_t *syms_of = s_syms[wid], *info_of = s_info[wid];
+    const uint32_t n_pack_waves = gridDim.x * 4u;
+    for (uint32_t fw = blockIdx.x * 4u + wid; fw < n_fill_waves; fw += n_pack_waves) {
+        // SwWave: {first_group, n_groups | G << 16, steps, class word}
+        const uint32_t first_group = waves[4 * (size_t)fw], n_groups = waves[4 * (size_t)fw + 1] & 0xffffu;
+        const uint32_t gc = (waves[4 * (size_t)fw + 1] >> 16) * (waves[4 * (size_t)fw + 3] & 0xffffu); // columns of a lane group
+        const uint32_t n_slots = n_groups * 2u;
+        bool all_dna = true;
+        // ---- pass 1: every pair of the wave: symbols of x, sentinels, the byte-0 check
+        for (uint32_t sl = 0; sl < n_slots; ++sl) {
+            const uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
+            const uint32_t h = sl & 1u, ll = rec[4 + h], out = rec[6 + h];
+            if (out >= n_pairs) { // vacant half: nothing to read, fits either kind of wave
+                if (lane == 0) info_of[sl] = 0x80000000u;
+                continue;
+            }
+            const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
+            const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
+            const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
+            const uint32_t xnl = lx && x[lx - 1] == '\n', ynl = ly && y[ly - 1] == '\n';
+            const uint32_t lxs = lx - xnl, lys = ly - ynl;
+            // distinct symbols of x', smallest first: repeatedly the smallest byte above the last one found
+            uint32_t syms = 0;
+            int nsym = 0;
+            bool bad = false, x_has_nl = false;
+            int last = -1;
+            for (int round = 0; round < 5; ++round) {
+                uint32_t mn = 256;
+                for (uint32_t i = lane; i < lxs; i += 64) {
+                    const uint32_t b = x[i];
+                    if (round == 0) {
+                        bad |= b == 0u;
+                        x_has_nl |= b == '\n';
+                    }
+                    if ((int)b > last && b < mn) mn = b;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                if (mn == 256) break;
+                if (round < 4) syms |= mn << (8 * round);
+                ++nsym; // 5 = "more than four"
+                last = (int)mn;
+            }
+            bool y_has_nl = false;
+            for (uint32_t i = lane; i < lys; i += 64) {
+                const uint32_t b = y[i];
+                bad |= b == 0u;
+                y_has_nl |= b == '\n';
+            }
+            if (__any(bad) && lane == 0) {
+                atomicAdd(&flag[0], 1u);
+                atomicMin(&flag[1], out);
+            }
+            const bool ok = nsym <= 4 && !(xnl && __any(y_has_nl)) && !(ynl && __any(x_has_nl)) && lx < 4096u;
+            all_dna = all_dna && ok;
+            if (lane == 0) {
+                syms_of[sl] = syms;
+                info_of[sl] = (uint32_t)nsym | (xnl << 4) | (ynl << 5);
+            }
+        }
+        // ---- pass 2: write the image, coded or as bytes
+        for (uint32_t sl = 0; sl < n_slots; ++sl) {
+            const uint32_t info = info_of[sl];
+            if (info & 0x80000000u) continue;
+            uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
+            const uint32_t h = sl & 1u, x_dw = rec[h], y_dw = rec[2 + h], ll = rec[4 + h], out = rec[6 + h];
+            const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
+            const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
+            const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
+            if (all_dna) {
+                const uint32_t syms = syms_of[sl];
+                const int nsym = (int)(info & 0xfu);
+                const uint32_t xnl = (info >> 4) & 1u, ynl = (info >> 5) & 1u, lxs = lx - xnl, lys = ly - ynl;
+                const uint32_t lead = gc - lxs; // right-aligned: x'[k] sits in column lead + k
+                for (uint32_t i = lane; i < y_dw - x_dw; i += 64) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t col = 4 * i + k;
+                        const uint32_t c = (col >= lead && col < gc) ? dna_code(x[col - lead], syms, nsym) + 4u * h : 0x0cu;
+                        v |= c << (8 * k);
+                    }
+                    img[x_dw + i] = v;
+                }
+                for (uint32_t i = lane; i < (ly + 3u) >> 2; i += 64) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        uint32_t sc = 31u;
+                        if (4 * i + k < lys) {
+                            const uint32_t c = dna_code(y[4 * i + k], syms, nsym);
+                            if (c < 4u) sc = 8u * (3u - c);
+                        }
+                        v |= sc << (8 * k);
+                    }
+                    img[y_dw + i] = v;
+                }
+                if (lane == 0) rec[4 + h] = lxs | ((xnl & ynl) << 13) | (xsec << 15) | (lys << 16);
+            } else {
+                bool bad = false; // (already reported in pass 1)
+                copy_seq<false>(img + x_dw, y_dw - x_dw, x, lx, nullptr, lane, bad);
+                copy_seq<false>(img + y_dw, (ly + 3u) >> 2, y, ly, nullptr, lane, bad);
+            }
+        }
+        if (all_dna && lane == 0) waves[4 * (size_t)fw + 3] |= 1u << 16;
+    }
+}
+
 } // namespace
+
+int agx_sw_pack_dna_launch(const uint8_t *raw, const uint64_t *off, uint64_t base, void *groups, void *waves, uint32_t n_waves,
+                           uint32_t n_pairs, uint32_t *img, uint32_t *flag, int n_cu, hipStream_t s)
+{
+    if (n_waves == 0) return 0;
+    static_assert(sizeof(SwWave) == 16 && sizeof(SwGroup2) == 32, "sw_pack_dna reads the records as words");
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n_waves + 3) / 4, (uint64_t)std::max(n_cu, 1) * 16u);
+    hipLaunchKernelGGL(sw_pack_dna, dim3(blocks), dim3(256), 0, s, raw, off, base, (uint32_t *)groups, (uint32_t *)waves, n_waves, n_pairs,
+                       img, flag);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int agx_sw_pack_launch(bool matrix, int slots, const uint8_t *raw, const uint64_t *off, uint64_t base, const void *groups,
                        uint32_t n_groups, uint32_t n_pairs, uint32_t *img, const uint8_t *code, uint32_t *flag, int n_cu,

@@ -29,6 +29,7 @@
 // [0x0400, 0x7c00) (agx_sw.cpp; always true for the reference's +1/-1/-3/-1 up to 2560 columns);
 // scores are bit-identical to the other kernels and to the reference.
 #include "agx_sw.h"
+#include <type_traits>
 
 namespace {
 
@@ -54,46 +55,107 @@ __device__ __forceinline__ uint32_t in_vgpr(uint32_t s)
     return r;
 }
 
-__device__ __forceinline__ uint32_t shr1u(uint32_t old, uint32_t v)
+// ---- the head of a step: this row's symbols and the four values a lane takes over from its left neighbour ----
+// A lane group's first lane (`start`) takes fresh values -- the row symbol / table, H = 0 and Q = -inf of column 0
+// (antidiagonalSmithWaterman.c:299-306) -- every other lane what its left neighbour held one step ago.  Written
+// out: v_cndmask_b32 with a DPP wave_shr:1 source does the shift and the choice in ONE instruction (the compiler's
+// own lowering was v_mov_dpp + v_cndmask per value, plus a compare against the row count per pair, a mask and a
+// shift for the symbol: 35 instructions a step next to the 361 of the cells at C = 38; these blocks have 6 and 5).
+// The DPP reads come at least three instructions after anything inside the block wrote a register (the gfx9 rule
+// is two wait states between a VALU write and a DPP read of the same register); what they read from outside was
+// written before the block began.
+#define AGX_DPP_TAKE " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+
+// FAST: the image holds y as SHIFT COUNTS: s = 8 * (3 - code), or 31 for "matches nothing" (a symbol x does not
+// contain, and every row beyond the sequence).  (delta << 24) >> s is the row's table: delta in the byte of the code
+// that matches, 0 elsewhere; delta < 128, so s = 31 leaves nothing.  The byte of the quad is picked by SDWA.
+#define AGX_FAST_HEAD(BYTE)                                                                                                  \
+    asm("v_lshrrev_b32_sdwa %4, %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" BYTE " src1_sel:DWORD\n"               \
+        "v_lshrrev_b32_sdwa %5, %7, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" BYTE " src1_sel:DWORD\n"               \
+        "s_mov_b64 vcc, %9\n"                                                                                                \
+        "v_cndmask_b32_dpp %0, %10, %12, vcc" AGX_DPP_TAKE "v_cndmask_b32_dpp %1, %11, %12, vcc" AGX_DPP_TAKE                \
+        "v_cndmask_b32_dpp %2, %2, %4, vcc" AGX_DPP_TAKE "v_cndmask_b32_dpp %3, %3, %5, vcc" AGX_DPP_TAKE                    \
+        : "=&v"(zl), "=&v"(fl), "+v"(ta), "+v"(tb), "=&v"(ma), "=&v"(mb)                                                     \
+        : "v"(rowsA), "v"(rowsB), "v"(kv), "s"(start_mask), "v"(z_last), "v"(f_last), "v"(z0v)                               \
+        : "vcc")
+
+template <int K>
+__device__ __forceinline__ void fast_head(uint32_t &zl, uint32_t &fl, uint32_t &ta, uint32_t &tb, uint32_t rowsA, uint32_t rowsB,
+                                          uint32_t kv, uint64_t start_mask, uint32_t z_last, uint32_t f_last, uint32_t z0v)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false); // wave_shr:1
+    uint32_t ma, mb;
+    if constexpr (K == 1)
+        AGX_FAST_HEAD("BYTE_1");
+    else if constexpr (K == 2)
+        AGX_FAST_HEAD("BYTE_2");
+    else if constexpr (K == 3)
+        AGX_FAST_HEAD("BYTE_3");
+    else
+        AGX_FAST_HEAD("BYTE_0");
 }
 
-template <int C>
-__device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
-                                         const SwWave w, int32_t *__restrict__ scores)
+// general: the image holds the symbols themselves (zero beyond a sequence -- byte 0 is no symbol, and padding
+// COLUMNS carry 0x100 << shift, which is no byte either); byte k of the two quads -> {a, 0, b, 0} << shift
+__device__ __forceinline__ void bytes_head(uint32_t &zl, uint32_t &fl, uint32_t &yc, uint32_t rowsA, uint32_t rowsB, uint32_t sel,
+                                           uint32_t sh_sym, uint64_t start_mask, uint32_t z_last, uint32_t f_last, uint32_t z0v)
 {
-    static_assert(C % 2 == 0, "the running maximum takes two columns per instruction");
-    constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
-    const int sh_sym = prm.shift;              // symbols live as byte << shift
-    const uint32_t row_pad = 0x100u << sh_sym; // never equals (byte << shift)
-    const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(prm.agf2), hd = in_vgpr(prm.hd2); // |ge|, |gf|, match + |gf|
-    const uint32_t bias = prm.bias2, delta = prm.delta2;
-    const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf)
-    const int lane = threadIdx.x & 63;
-    const int G = w.G;
-    const int grp = lane / G;
-    const int gl = lane - grp * G;
-    const bool active = grp < (int)w.n_groups;
-    const bool start = gl == 0;
-    const bool feeder = active && start;
+    uint32_t fresh;
+    asm("v_perm_b32 %3, %5, %4, %6\n"
+        "v_lshlrev_b32 %3, %7, %3\n"
+        "s_mov_b64 vcc, %8\n"
+        "v_cndmask_b32_dpp %0, %9, %11, vcc" AGX_DPP_TAKE "v_cndmask_b32_dpp %1, %10, %11, vcc" AGX_DPP_TAKE
+        "v_cndmask_b32_dpp %2, %2, %3, vcc" AGX_DPP_TAKE
+        : "=&v"(zl), "=&v"(fl), "+v"(yc), "=&v"(fresh)
+        : "v"(rowsA), "v"(rowsB), "s"(sel), "v"(sh_sym), "s"(start_mask), "v"(z_last), "v"(f_last), "v"(z0v)
+        : "vcc");
+}
 
-    SwGroup2 g;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) g.x_dw[k] = g.y_dw[k] = g.lx_ly[k] = g.out[k] = 0;
-    if (active) g = groups[w.first_group + grp];
+// FAST = the wave's pairs all passed the pack kernel's DNA test (agx_sw_pack_kernel.hip, sw_pack_dna): at most four
+// distinct symbols in the shorter sequence, a trailing newline sentinel at most at the very end of either.  The
+// image then holds CODES, the sentinels stripped:
+//   x  as v_perm_b32 selector bytes -- code 0..3 for pair A, 4 + code for pair B, 0x0c (the constant 0) for a padding
+//      column -- RIGHT-aligned in the group's G * C columns: padding columns on the left behave exactly like column
+//      0 (H = 0, Q = -inf), and the last symbol always sits in the last column of the group's last lane;
+//   y  as shift counts (fast_head).
+// The row table M (byte c = delta if the row symbol is x's code c, else 0) travels down the lanes, and ONE
+// v_perm_b32 per column yields the match bonus of BOTH pairs (selector byte 0 picks M_A[code], byte 2 picks
+// M_B[code]) where the general cell spends v_xor_b32 + v_pk_min_u16: 9.5 instead of 10.5 instructions per two
+// cells.  The stripped sentinels are put back at the end: a final newline aligns with nothing but the other
+// sequence's final newline, so the score is max(best, H[lx'][ly'] + match) when both had one
+// (antidiagonalSmithWaterman.c:229-247 keeps the newline as a symbol), best otherwise.  H[lx'][ly']
+// is what the group's last lane holds in its last column after step ly' - 1 + (G - 1).
+template <int C, bool FAST>
+__device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 &g, const SwWave &w,
+                                         int32_t *__restrict__ scores, int lane, int G, int gl, bool active, bool start, bool feeder)
+{
+    constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
+    const uint32_t sh_sym = prm.shift;         // general: symbols live as byte << shift
+    const uint32_t col_pad = 0x100u << sh_sym; // never equals (byte << shift)
+    const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(prm.agf2);                     // |ge|, |gf|
+    const uint32_t hd = in_vgpr(FAST ? prm.hd2 - prm.delta2 : prm.hd2);                // mismatch + |gf| / match + |gf|
+    const uint32_t bias = prm.bias2, delta = prm.delta2;
+    const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf), both halves
+    const uint32_t z0v = in_vgpr(z0);
+    const uint32_t kv = in_vgpr((prm.delta2 & 0xffu) << 24); // FAST: the table source
+    const uint64_t start_mask = __ballot(start);
+    const uint32_t lx_mask = FAST ? 0xfffu : 0x7fffu;
+    const int lxA = (int)(g.lx_ly[0] & lx_mask), lxB = (int)(g.lx_ly[1] & lx_mask);
     const int lyA = (int)(g.lx_ly[0] >> 16), lyB = (int)(g.lx_ly[1] >> 16);
     const int nqA = (lyA + 3) >> 2, nqB = (lyB + 3) >> 2;
 
-    // this lane's C symbols of both short sequences -> one register per column: (a << shift) | (b << shift) << 16
+    // this lane's C symbols of both short sequences -> one register per column:
+    //   general: (a << shift) | (b << shift) << 16;   FAST: the v_perm_b32 selector {sel_a, 0x0c, sel_b, 0x0c}
     uint32_t xq[C];
     {
         const uint32_t o = (uint32_t)gl * C, d0 = o >> 2, sh = o & 3u;
+        // FAST: a vacant half (its record points at the zero block, offset 0) and idle lanes read zeros: all padding
+        const uint32_t fillA = (FAST && !(active && g.x_dw[0])) ? 0x0c0c0c0cu : 0u;
+        const uint32_t fillB = (FAST && !(active && g.x_dw[1])) ? 0x0c0c0c0cu : 0u;
         uint32_t ra[XW + 1], rb[XW + 1];
 #pragma unroll
         for (int k = 0; k <= XW; ++k) {
-            ra[k] = active ? img[g.x_dw[0] + d0 + k] : 0u;
-            rb[k] = active ? img[g.x_dw[1] + d0 + k] : 0u;
+            ra[k] = (active ? img[g.x_dw[0] + d0 + k] : 0u) | fillA;
+            rb[k] = (active ? img[g.x_dw[1] + d0 + k] : 0u) | fillB;
         }
 #pragma unroll
         for (int k = 0; k < XW; ++k) {
@@ -101,14 +163,27 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
             const uint32_t b = __builtin_amdgcn_alignbyte(rb[k + 1], rb[k], sh);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (4 * k + i < C)
-                    xq[4 * k + i] = ((((a >> (8 * i)) & 0xffu) << sh_sym) | ((((b >> (8 * i)) & 0xffu) << sh_sym) << 16));
+                if (4 * k + i < C) {
+                    const uint32_t ca = (a >> (8 * i)) & 0xffu, cb = (b >> (8 * i)) & 0xffu;
+                    uint32_t v;
+                    if constexpr (FAST)
+                        v = ca | 0x0c00u | (cb << 16) | 0x0c000000u;
+                    else {
+                        const int col = (int)o + 4 * k + i;
+                        v = (col < lxA ? ca << sh_sym : col_pad) | ((col < lxB ? cb << sh_sym : col_pad) << 16);
+                    }
+                    // opaque to the compiler: left visible, it keeps the length tests as lane masks and rebuilds
+                    // every register in every step to save registers
+                    asm volatile("" : "+v"(v));
+                    xq[4 * k + i] = v;
+                }
         }
     }
 
     const uint32_t *ypA = img + g.y_dw[0], *ypB = img + g.y_dw[1];
-    auto quadA = [&](int q) -> uint32_t { return (feeder && q < nqA) ? ypA[q] : 0u; };
-    auto quadB = [&](int q) -> uint32_t { return (feeder && q < nqB) ? ypB[q] : 0u; };
+    const uint32_t no_row = FAST ? 0x1f1f1f1fu : 0u; // rows beyond the sequence match nothing
+    auto quadA = [&](int q) -> uint32_t { return (feeder && q < nqA) ? ypA[q] : no_row; };
+    auto quadB = [&](int q) -> uint32_t { return (feeder && q < nqB) ? ypB[q] : no_row; };
 
     // state per owned column, both pairs packed, biased: z = H + gf + B and e = max(P, 0) + B
     uint32_t z[C], e[C];
@@ -120,7 +195,15 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
     // the horizontal gap state needs no clamp: Q >= z_left >= gf always; "no gap open yet" is Q = gf,
     // whose successor gf + ge loses against every z_left
     uint32_t z_last = z0, f_last = z0, diag_in = z0, best = z0;
-    uint32_t yc_prev = row_pad | (row_pad << 16);
+    uint32_t yc = 0;         // general: the row symbols of both pairs
+    uint32_t ta = 0, tb = 0; // FAST: the row tables of pair A / pair B
+
+    // FAST: the step after which the group's last lane holds H[lx'][ly'] in its last column (bit 13 of the record:
+    // both sequences ended with the sentinel); a stripped side that is empty leaves the corner at H = 0
+    const bool last = active && gl == G - 1;
+    const bool nlA = FAST && last && ((g.lx_ly[0] >> 13) & 1u), nlB = FAST && last && ((g.lx_ly[1] >> 13) & 1u);
+    const int capA_t = (nlA && lxA > 0 && lyA > 0) ? lyA + G - 2 : -1, capB_t = (nlB && lxB > 0 && lyB > 0) ? lyB + G - 2 : -1;
+    uint32_t cornerA = z0, cornerB = z0;
 
     uint32_t a0 = quadA(0), a1 = quadA(1), a2 = quadA(2);
     uint32_t b0 = quadB(0), b1 = quadB(1), b2 = quadB(2);
@@ -128,20 +211,14 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
     uint32_t rowsA = 0, rowsB = 0;
     int t = 0;
 
-    auto step = [&]() __attribute__((always_inline)) {
-        const uint32_t fa = (t < lyA) ? ((rowsA & 0xffu) << sh_sym) : row_pad;
-        const uint32_t fb = (t < lyB) ? ((rowsB & 0xffu) << sh_sym) : row_pad;
-        rowsA >>= 8;
-        rowsB >>= 8;
-        const uint32_t fresh = fa | (fb << 16);
-        uint32_t zl = shr1u(0, z_last);
-        uint32_t fl = shr1u(0, f_last);
-        uint32_t yc = shr1u(fresh, yc_prev);
-        if (start) { // column 0: H = 0, Q = -inf (antidiagonalSmithWaterman.c:299-306)
-            zl = z0;
-            fl = z0;
-            yc = fresh;
-        }
+    // K = which byte of the quads this step reads (the tail loop shifts the quads instead: K = 0)
+    auto step = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;
+        uint32_t zl, fl;
+        if constexpr (FAST)
+            fast_head<K>(zl, fl, ta, tb, rowsA, rowsB, kv, start_mask, z_last, f_last, z0v);
+        else
+            bytes_head(zl, fl, yc, rowsA, rowsB, 0x0c040c00u + 0x00010001u * K, sh_sym, start_mask, z_last, f_last, z0v);
         uint32_t zd = diag_in; // H[r-1][first column - 1] + gf
         diag_in = zl;
         uint32_t zleft = zl, f = fl;
@@ -153,8 +230,11 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
                 const uint32_t up = z[j + k];
                 const uint32_t ev = umax3(up, e[j + k] - ge, bias); // reference P, :313, clamped at 0
                 f = umax2(zleft, f - ge);                          // reference Q, :321
-                const uint32_t m = umin2(xq[j + k] ^ yc, delta);   // 0 on a match, match - mismatch otherwise
-                const uint32_t u = (zd + hd) - m;                  // H_diag + match / + mismatch, :332
+                uint32_t u;                                        // H_diag + match / + mismatch, :332
+                if constexpr (FAST)
+                    u = (zd + hd) + __builtin_amdgcn_perm(tb, ta, xq[j + k]); // mismatch, plus delta on a match
+                else
+                    u = (zd + hd) - umin2(xq[j + k] ^ yc, delta); // match, minus delta on a mismatch
                 const uint32_t v = umax3(ev, f, u);                // :333 (ev >= B carries the zero floor)
                 zn[k] = v - gf;
                 e[j + k] = ev;
@@ -164,9 +244,12 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
             }
             best = umax3(best, zn[0], zn[1]); // :335
         }
+        if constexpr (FAST) {
+            cornerA = t == capA_t ? zleft : cornerA;
+            cornerB = t == capB_t ? zleft : cornerB;
+        }
         z_last = zleft;
         f_last = f;
-        yc_prev = yc;
         ++t;
     };
 
@@ -180,14 +263,29 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
         b0 = b1;
         b1 = b2;
         b2 = quadB(q + 3);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) step();
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
     }
     rowsA = a0;
     rowsB = b0;
 #pragma unroll 1
-    while (t < steps) step();
+    while (t < steps) {
+        step(std::integral_constant<int, 0>{});
+        rowsA >>= 8;
+        rowsB >>= 8;
+    }
 
+    if constexpr (FAST) {
+        // the stripped sentinels: when both sequences ended with one, the two newlines align after the corner cell.
+        // H_corner + match as a z value is z_corner + match.
+        const uint32_t match2 = prm.hd2 - prm.agf2; // (match + |gf|) - |gf| in both halves
+        uint32_t cand = z0;
+        if (nlA) cand = (cand & 0xffff0000u) | ((cornerA + match2) & 0xffffu);
+        if (nlB) cand = (cand & 0xffffu) | ((cornerB + match2) & 0xffff0000u);
+        best = umax2(best, cand);
+    }
     // max over the group's lanes (G need not be a power of two), both halves at once
     for (int o = 1; o < G; o <<= 1) {
         const uint32_t other = (uint32_t)__shfl_down((int)best, o);
@@ -198,6 +296,30 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
         scores[g.out[0]] = (int)(best & 0xffffu) - off;
         scores[g.out[1]] = (int)(best >> 16) - off; // a group without a second pair points this at the spare slot
     }
+}
+
+template <int C>
+__device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
+                                         const SwWave w, int32_t *__restrict__ scores)
+{
+    static_assert(C % 2 == 0, "the running maximum takes two columns per instruction");
+    const int lane = threadIdx.x & 63;
+    const int G = w.G;
+    const int grp = lane / G;
+    const int gl = lane - grp * G;
+    const bool active = grp < (int)w.n_groups;
+    const bool start = gl == 0;
+    const bool feeder = active && start;
+
+    SwGroup2 g;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) g.x_dw[k] = g.y_dw[k] = g.lx_ly[k] = g.out[k] = 0;
+    if (active) g = groups[w.first_group + grp];
+    // bit 16 of the wave record's class word: set by the pack kernel when every pair of the wave is DNA-coded
+    if (__builtin_amdgcn_readfirstlane(w.reserved >> 16) & 1u)
+        pk2_fill<C, true>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+    else
+        pk2_fill<C, false>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
 }
 
 template <int C>
@@ -224,7 +346,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
     const SwWave w = waves[wave];
-    switch (__builtin_amdgcn_readfirstlane(w.reserved)) { // columns per lane of this wave
+    switch (__builtin_amdgcn_readfirstlane(w.reserved) & 0xffffu) { // columns per lane of this wave
 #define AGX_SW_CASE(CC) \
     case CC: pk2_body<CC>(prm, img, groups, w, scores); break;
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
