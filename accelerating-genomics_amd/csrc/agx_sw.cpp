@@ -241,6 +241,7 @@ struct agx_sw_batch {
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
     DevBuf table; // substitution-matrix mode: kSwMatDim^2 int16 entries
+    bool rising = false; // biased packed fill: the variant whose stored values rise by |ge| per step (agx_sw_pk2_kernel.hip, RISE)
     PinBuf out_stage; // page-locked landing block of the scores, taken at create: agx_sw_batch_scores allocates nothing
                       // (a first hipHostMalloc costs milliseconds, and hipvers' timed window is launch -> scores)
     bool matrix = false;
@@ -476,6 +477,10 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     int family = want == AGX_SW_KERNEL_INT32 ? 0 : want == AGX_SW_KERNEL_PACKED_SIGNED ? 1 : 2;
     if (matrix || longest_short > (uint32_t)kSwPackedMaxShort) family = 0; // the matrix lookup exists in the int32 kernel only
     if (family == 2 && !((int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00)) family = 1;
+    // ... and its rising-offset variant adds (steps + 2) |ge| on top, steps <= longest longer side + 63
+    bool rising = family == 2 &&
+                  (int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf + ((int64_t)longest_long + 66) * -(int64_t)prm.ge < 0x7c00;
+    if (const char *e = agx_tune("AGX_SW_RISE")) rising = rising && e[0] != '0';
     const bool packed = family != 0;
     const double *costs = class_costs(family);
     const int slots = packed ? 2 : 1;
@@ -521,6 +526,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     b->ctx = ctx;
     b->n_pairs = n_pairs;
     b->family = family;
+    b->rising = rising;
     b->matrix = matrix != nullptr;
     b->prm = prm;
 
@@ -1092,9 +1098,9 @@ int agx_sw_batch_launch(agx_sw_batch *b)
             r = agx_sw_mat_launch_class(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
                                         (const int16_t *)b->table.p, st);
         else if (b->family == 2 && cl.C == 0)
-            r = agx_sw_pk2_launch_any(b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+            r = agx_sw_pk2_launch_any(b->rising, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 2)
-            r = agx_sw_pk2_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+            r = agx_sw_pk2_launch_class(cl.C, b->rising, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 1)
             r = agx_sw_pk_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else

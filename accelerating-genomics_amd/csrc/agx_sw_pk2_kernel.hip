@@ -124,18 +124,29 @@ __device__ __forceinline__ void bytes_head(uint32_t &zl, uint32_t &fl, uint32_t 
 // sequence's final newline, so the score is max(best, H[lx'][ly'] + match) when both had one
 // (antidiagonalSmithWaterman.c:229-247 keeps the newline as a symbol), best otherwise.  H[lx'][ly']
 // is what the group's last lane holds in its last column after step ly' - 1 + (G - 1).
-template <int C, bool FAST>
+//
+// RISE = "rising offsets": every stored value additionally carries an offset that grows by |ge| per step, the same in
+// all lanes: r(t) = (t + 2) |ge|, on z of step t; r(t - 1) on e, f and H of step t.  The vertical gap then needs no
+// subtraction at all -- P_new + r(t) = max(z_up + r(t), (P + r(t-1))) since r(t) - |ge| = r(t - 1) -- the horizontal gap
+// subtracts after its maximum instead of before, the diagonal is unchanged (z_diag carries r(t - 1), which is H's
+// offset), and z = H - (|gf| - |ge|).  One v_sub_u32 less per two cells; per STEP the floor, the column-0 value and
+// the running maximum rise by |ge| and the two values handed to the right neighbour (used one step later) are
+// lifted by |ge|: five instructions.  The host asks for this variant when B + the largest score + (steps + 2) |ge| stays
+// below 0x7c00 (agx_sw.cpp) -- rows up to about 27 000 with the reference's scores; beyond, the plain cell.
+template <int C, bool FAST, bool RISE>
 __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 &g, const SwWave &w,
                                          int32_t *__restrict__ scores, int lane, int G, int gl, bool active, bool start, bool feeder)
 {
     constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
     const uint32_t sh_sym = prm.shift;         // general: symbols live as byte << shift
     const uint32_t col_pad = 0x100u << sh_sym; // never equals (byte << shift)
-    const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(prm.agf2);                     // |ge|, |gf|
+    const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(RISE ? prm.agf2 - prm.age2 : prm.agf2); // |ge|; |gf| (RISE: |gf| - |ge|)
     const uint32_t hd = in_vgpr(FAST ? prm.hd2 - prm.delta2 : prm.hd2);                // mismatch + |gf| / match + |gf|
     const uint32_t bias = prm.bias2, delta = prm.delta2;
     const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf), both halves
-    const uint32_t z0v = in_vgpr(z0);
+    uint32_t zb = in_vgpr(RISE ? z0 + 2u * prm.age2 : z0);        // column 0 as the first lane sees it: z0 + r(t)
+    uint32_t floorv = in_vgpr(RISE ? bias + prm.age2 : bias);     // P~ >= 0 at H's offset: B + r(t - 1)
+    const uint32_t z_init = RISE ? z0 + prm.age2 : z0;            // H = 0 one step before the first: z0 + r(-1)
     const uint32_t kv = in_vgpr((prm.delta2 & 0xffu) << 24); // FAST: the table source
     const uint64_t start_mask = __ballot(start);
     const uint32_t lx_mask = FAST ? 0xfffu : 0x7fffu;
@@ -189,12 +200,12 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     uint32_t z[C], e[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        z[j] = z0;
-        e[j] = bias;
+        z[j] = z_init;
+        e[j] = bias; // anything up to the first floor
     }
     // the horizontal gap state needs no clamp: Q >= z_left >= gf always; "no gap open yet" is Q = gf,
     // whose successor gf + ge loses against every z_left
-    uint32_t z_last = z0, f_last = z0, diag_in = z0, best = z0;
+    uint32_t z_last = zb, f_last = zb, diag_in = z_init, best = z_init;
     uint32_t yc = 0;         // general: the row symbols of both pairs
     uint32_t ta = 0, tb = 0; // FAST: the row tables of pair A / pair B
 
@@ -203,7 +214,7 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     const bool last = active && gl == G - 1;
     const bool nlA = FAST && last && ((g.lx_ly[0] >> 13) & 1u), nlB = FAST && last && ((g.lx_ly[1] >> 13) & 1u);
     const int capA_t = (nlA && lxA > 0 && lyA > 0) ? lyA + G - 2 : -1, capB_t = (nlB && lxB > 0 && lyB > 0) ? lyB + G - 2 : -1;
-    uint32_t cornerA = z0, cornerB = z0;
+    uint32_t cornerA = z_init, cornerB = z_init;
 
     uint32_t a0 = quadA(0), a1 = quadA(1), a2 = quadA(2);
     uint32_t b0 = quadB(0), b1 = quadB(1), b2 = quadB(2);
@@ -216,9 +227,10 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         constexpr int K = decltype(kc)::value;
         uint32_t zl, fl;
         if constexpr (FAST)
-            fast_head<K>(zl, fl, ta, tb, rowsA, rowsB, kv, start_mask, z_last, f_last, z0v);
+            fast_head<K>(zl, fl, ta, tb, rowsA, rowsB, kv, start_mask, z_last, f_last, zb);
         else
-            bytes_head(zl, fl, yc, rowsA, rowsB, 0x0c040c00u + 0x00010001u * K, sh_sym, start_mask, z_last, f_last, z0v);
+            bytes_head(zl, fl, yc, rowsA, rowsB, 0x0c040c00u + 0x00010001u * K, sh_sym, start_mask, z_last, f_last, zb);
+        if constexpr (RISE) best += ge;
         uint32_t zd = diag_in; // H[r-1][first column - 1] + gf
         diag_in = zl;
         uint32_t zleft = zl, f = fl;
@@ -228,8 +240,14 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const uint32_t up = z[j + k];
-                const uint32_t ev = umax3(up, e[j + k] - ge, bias); // reference P, :313, clamped at 0
-                f = umax2(zleft, f - ge);                          // reference Q, :321
+                uint32_t ev; // reference P, :313, clamped at 0;  reference Q, :321
+                if constexpr (RISE) {
+                    ev = umax3(up, e[j + k], floorv);
+                    f = umax2(zleft, f) - ge;
+                } else {
+                    ev = umax3(up, e[j + k] - ge, bias);
+                    f = umax2(zleft, f - ge);
+                }
                 uint32_t u;                                        // H_diag + match / + mismatch, :332
                 if constexpr (FAST)
                     u = (zd + hd) + __builtin_amdgcn_perm(tb, ta, xq[j + k]); // mismatch, plus delta on a match
@@ -248,8 +266,15 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
             cornerA = t == capA_t ? zleft : cornerA;
             cornerB = t == capB_t ? zleft : cornerB;
         }
-        z_last = zleft;
-        f_last = f;
+        if constexpr (RISE) { // what the right neighbour reads is used one step later
+            z_last = zleft + ge;
+            f_last = f + ge;
+            floorv += ge;
+            zb += ge;
+        } else {
+            z_last = zleft;
+            f_last = f;
+        }
         ++t;
     };
 
@@ -281,9 +306,10 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         // the stripped sentinels: when both sequences ended with one, the two newlines align after the corner cell.
         // H_corner + match as a z value is z_corner + match.
         const uint32_t match2 = prm.hd2 - prm.agf2; // (match + |gf|) - |gf| in both halves
-        uint32_t cand = z0;
-        if (nlA) cand = (cand & 0xffff0000u) | ((cornerA + match2) & 0xffffu);
-        if (nlB) cand = (cand & 0xffffu) | ((cornerB + match2) & 0xffff0000u);
+        const uint32_t ge1 = RISE ? prm.age2 & 0xffffu : 0u; // the corner was taken at offset r(cap_t), best stands at r(steps - 1)
+        uint32_t cand = best;
+        if (nlA) cand = (cand & 0xffff0000u) | ((cornerA + match2 + (uint32_t)(steps - 1 - capA_t) * ge1) & 0xffffu);
+        if (nlB) cand = (cand & 0xffffu) | ((cornerB + match2 + ((uint32_t)(steps - 1 - capB_t) * ge1 << 16)) & 0xffff0000u);
         best = umax2(best, cand);
     }
     // max over the group's lanes (G need not be a power of two), both halves at once
@@ -292,13 +318,13 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         if (gl + o < G) best = umax2(best, other);
     }
     if (feeder) {
-        const int off = (int)(z0 & 0xffffu); // stored value of H = 0
+        const int off = (int)(z0 & 0xffffu) + (RISE ? (steps + 1) * (int)(prm.age2 & 0xffffu) : 0); // stored value of H = 0, at r(steps - 1)
         scores[g.out[0]] = (int)(best & 0xffffu) - off;
         scores[g.out[1]] = (int)(best >> 16) - off; // a group without a second pair points this at the spare slot
     }
 }
 
-template <int C>
+template <int C, bool RISE>
 __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
                                          const SwWave w, int32_t *__restrict__ scores)
 {
@@ -317,12 +343,12 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
     if (active) g = groups[w.first_group + grp];
     // bit 16 of the wave record's class word: set by the pack kernel when every pair of the wave is DNA-coded
     if (__builtin_amdgcn_readfirstlane(w.reserved >> 16) & 1u)
-        pk2_fill<C, true>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, true, RISE>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
     else
-        pk2_fill<C, false>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, false, RISE>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
 }
 
-template <int C>
+template <int C, bool RISE>
 __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uint32_t *__restrict__ img,
                                                    const SwGroup2 *__restrict__ groups,
                                                    const SwWave *__restrict__ waves, uint32_t n_waves,
@@ -330,7 +356,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
-    pk2_body<C>(prm, img, groups, waves[wave], scores);
+    pk2_body<C, RISE>(prm, img, groups, waves[wave], scores);
 }
 
 // Mixed batches: ONE launch for every lane-tiling class.  Each wavefront reads its class (columns per lane)
@@ -338,6 +364,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 // (100 VGPRs, five waves per SIMD -- the fill is bound by VALU issue, not by occupancy).  Against one launch
 // per class this (a) lets the planner use every width, so padding shrinks, (b) dispatches the waves of ALL
 // classes longest first, (c) has no stream fork/join and no per-launch ramp.
+template <bool RISE>
 __global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const uint32_t *__restrict__ img,
                                                        const SwGroup2 *__restrict__ groups,
                                                        const SwWave *__restrict__ waves, uint32_t n_waves,
@@ -348,40 +375,43 @@ __global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const
     const SwWave w = waves[wave];
     switch (__builtin_amdgcn_readfirstlane(w.reserved) & 0xffffu) { // columns per lane of this wave
 #define AGX_SW_CASE(CC) \
-    case CC: pk2_body<CC>(prm, img, groups, w, scores); break;
+    case CC: pk2_body<CC, RISE>(prm, img, groups, w, scores); break;
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: break;
     }
 }
 
-template <int C>
+template <int C, bool RISE>
 int launch(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
            int32_t *scores, hipStream_t s)
 {
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(sw_fill_pk2<C>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    hipLaunchKernelGGL((sw_fill_pk2<C, RISE>), dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 } // namespace
 
-int agx_sw_pk2_launch_any(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+int agx_sw_pk2_launch_any(bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
                           int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL(sw_fill_pk2_any, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    if (rising)
+        hipLaunchKernelGGL(sw_fill_pk2_any<true>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    else
+        hipLaunchKernelGGL(sw_fill_pk2_any<false>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int agx_sw_pk2_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+int agx_sw_pk2_launch_class(int cols_per_lane, bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_SW_CASE(CC) \
-    case CC: return launch<CC>(prm, img, groups, waves, n_waves, scores, s);
+    case CC: return rising ? launch<CC, true>(prm, img, groups, waves, n_waves, scores, s) : launch<CC, false>(prm, img, groups, waves, n_waves, scores, s);
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: return -2;
