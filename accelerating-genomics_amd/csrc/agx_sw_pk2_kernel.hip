@@ -39,12 +39,14 @@ __device__ __forceinline__ u16x2 as_v(uint32_t v) { return __builtin_bit_cast(u1
 __device__ __forceinline__ uint32_t as_u(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ uint32_t umax2(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_v(a), as_v(b))); }
 __device__ __forceinline__ uint32_t umin2(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_min(as_v(a), as_v(b))); }
-// exact unsigned max3 per half for patterns of positive normal half-precision numbers (see above)
+// exact unsigned max3 per half for patterns of positive normal half-precision numbers (see above): v_pk_maximum3_f16.
+// Through the builtin rather than inline assembly: after every asm block the compiler's hazard pass pads with an
+// s_nop (17 a step at 38 columns).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c)
 {
-    uint32_t r;
-    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
 // a wave-uniform constant forced into a VGPR: with an SGPR or literal operand v_add/v_sub_u32 fall back
 // to the 4-cycle rate ("v_subrev_u32 SGPR constant" in the microbenchmark)
@@ -129,9 +131,11 @@ __device__ __forceinline__ void bytes_head(uint32_t &zl, uint32_t &fl, uint32_t 
 // all lanes: r(t) = (t + 2) |ge|, on z of step t; r(t - 1) on e, f and H of step t.  The vertical gap then needs no
 // subtraction at all -- P_new + r(t) = max(z_up + r(t), (P + r(t-1))) since r(t) - |ge| = r(t - 1) -- the horizontal gap
 // subtracts after its maximum instead of before, the diagonal is unchanged (z_diag carries r(t - 1), which is H's
-// offset), and z = H - (|gf| - |ge|).  One v_sub_u32 less per two cells; per STEP the floor, the column-0 value and
-// the running maximum rise by |ge| and the two values handed to the right neighbour (used one step later) are
-// lifted by |ge|: five instructions.  The host asks for this variant when B + the largest score + (steps + 2) |ge| stays
+// offset), and z = H - (|gf| - |ge|).  One v_sub_u32 less per two cells; per STEP the floor, the column-0 value
+// (wave-uniform: a scalar add) and the running maximum rise by |ge|.  What a lane takes over from its left
+// neighbour was made one step earlier and is |ge| behind: in the lane's first column that lag cancels the horizontal
+// gap's subtraction (max(z_left + |ge|, f_left + |ge|) - |ge|), and the diagonal adds |ge| through its constant.
+// The host asks for this variant when B + the largest score + (steps + 2) |ge| stays
 // below 0x7c00 (agx_sw.cpp) -- rows up to about 27 000 with the reference's scores; beyond, the plain cell.
 template <int C, bool FAST, bool RISE>
 __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 &g, const SwWave &w,
@@ -144,8 +148,10 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     const uint32_t hd = in_vgpr(FAST ? prm.hd2 - prm.delta2 : prm.hd2);                // mismatch + |gf| / match + |gf|
     const uint32_t bias = prm.bias2, delta = prm.delta2;
     const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf), both halves
-    uint32_t zb = in_vgpr(RISE ? z0 + 2u * prm.age2 : z0);        // column 0 as the first lane sees it: z0 + r(t)
-    uint32_t floorv = in_vgpr(RISE ? bias + prm.age2 : bias);     // P~ >= 0 at H's offset: B + r(t - 1)
+    const uint32_t hd0 = in_vgpr((FAST ? prm.hd2 - prm.delta2 : prm.hd2) + (RISE ? prm.age2 : 0u)); // first column's diagonal
+    uint32_t zb = RISE ? z0 + prm.age2 : z0;                      // column 0 as the first lane takes it over: z0 + r(t - 1)
+    uint32_t floorv = in_vgpr(RISE ? bias + prm.age2 : bias);     // P~ >= 0 at H's offset: B + r(t - 1); in a VGPR: as an
+                                                                  // SGPR operand it drew an s_nop after every group of four
     const uint32_t z_init = RISE ? z0 + prm.age2 : z0;            // H = 0 one step before the first: z0 + r(-1)
     const uint32_t kv = in_vgpr((prm.delta2 & 0xffu) << 24); // FAST: the table source
     const uint64_t start_mask = __ballot(start);
@@ -205,7 +211,7 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     }
     // the horizontal gap state needs no clamp: Q >= z_left >= gf always; "no gap open yet" is Q = gf,
     // whose successor gf + ge loses against every z_left
-    uint32_t z_last = zb, f_last = zb, diag_in = z_init, best = z_init;
+    uint32_t z_last = z_init, f_last = z_init, diag_in = z0, best = z_init;
     uint32_t yc = 0;         // general: the row symbols of both pairs
     uint32_t ta = 0, tb = 0; // FAST: the row tables of pair A / pair B
 
@@ -243,16 +249,17 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
                 uint32_t ev; // reference P, :313, clamped at 0;  reference Q, :321
                 if constexpr (RISE) {
                     ev = umax3(up, e[j + k], floorv);
-                    f = umax2(zleft, f) - ge;
+                    f = umax2(zleft, f);
+                    if (j + k > 0) f -= ge; // (first column: see above)
                 } else {
                     ev = umax3(up, e[j + k] - ge, bias);
                     f = umax2(zleft, f - ge);
                 }
                 uint32_t u;                                        // H_diag + match / + mismatch, :332
                 if constexpr (FAST)
-                    u = (zd + hd) + __builtin_amdgcn_perm(tb, ta, xq[j + k]); // mismatch, plus delta on a match
+                    u = (zd + (j + k ? hd : hd0)) + __builtin_amdgcn_perm(tb, ta, xq[j + k]); // mismatch, plus delta on a match
                 else
-                    u = (zd + hd) - umin2(xq[j + k] ^ yc, delta); // match, minus delta on a mismatch
+                    u = (zd + (j + k ? hd : hd0)) - umin2(xq[j + k] ^ yc, delta); // match, minus delta on a mismatch
                 const uint32_t v = umax3(ev, f, u);                // :333 (ev >= B carries the zero floor)
                 zn[k] = v - gf;
                 e[j + k] = ev;
@@ -266,14 +273,11 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
             cornerA = t == capA_t ? zleft : cornerA;
             cornerB = t == capB_t ? zleft : cornerB;
         }
-        if constexpr (RISE) { // what the right neighbour reads is used one step later
-            z_last = zleft + ge;
-            f_last = f + ge;
+        z_last = zleft;
+        f_last = f;
+        if constexpr (RISE) {
             floorv += ge;
-            zb += ge;
-        } else {
-            z_last = zleft;
-            f_last = f;
+            zb += prm.age2;
         }
         ++t;
     };
