@@ -4,6 +4,7 @@
 #include "agx_phmm.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -190,6 +191,7 @@ struct agx_phmm_batch {
     bool gatk_prior = false;
     int64_t n_pairs = 0;
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
+    bool scaled = false;          // ... and its fill runs the scaled cell (no Phred-0 gap-continuation quality in the batch)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
     DevBuf img, sums, logs, lut, counter; // logs: float modes only (log10 taken on the device)
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
@@ -371,8 +373,15 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         agx_set_error("agx_phmm_batch_create: NULL track");
         return AGX_E_ARG;
     }
+    // packed float fill: its scaled cell divides by 1 - Qg (agx_phmm_pk_kernel.hip), so a gap-continuation quality of
+    // Phred 0 or below anywhere in the batch keeps the plain cell
+    std::atomic<bool> gcp_zero{false};
     if (have_tracks) {
         agx_parallel_for((int64_t)n_reads, 2048, [&](int64_t ra, int64_t rz, int) {
+            bool zero = false;
+            for (int64_t r = ra; r < rz && packed && !probs; ++r)
+                for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k) zero |= d->q_gcp[k] <= (uint8_t)'!';
+            if (zero) gcp_zero.store(true, std::memory_order_relaxed);
             for (int64_t r = ra; r < rz; ++r) {
                 const uint64_t o = d->read_off[r];
                 const size_t R = (size_t)(d->read_off[r + 1] - o), trk = (R + 3) / 4;
@@ -697,6 +706,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->probs = probs;
     b->gatk_prior = gatk_prior;
     b->packed = packed;
+    b->scaled = packed && !gcp_zero.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
     b->separate_rescue = packed;
     b->n_pairs = n_pairs;
     b->main.launches = pmain.launches;
@@ -890,7 +900,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         for (const ClassLaunch &cl : b->main.launches) {
             hipStream_t st = fan.stream(k++);
             if (b->packed) {
-                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->scaled, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
                                                        (const PhTab *)b->main.tabs.p,
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
                                                        mis_for_f, (double *)b->sums.p, cl.lds, st);

@@ -100,59 +100,99 @@ __device__ __forceinline__ uint32_t dna_code(uint32_t b, uint32_t syms, int nsym
     return c;
 }
 
+// calls f(byte) for the n bytes at p, fetched as aligned words (p has any alignment; the words that hold the first
+// and the last byte lie inside the upload: it starts on a word and ends with a spare one)
+template <class F>
+__device__ __forceinline__ void for_each_byte(const uint8_t *p, uint32_t n, F f)
+{
+    const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), total = lead + n;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p - lead);
+    for (uint32_t w = 0; 4u * w < total; ++w) {
+        const uint32_t v = q[w];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t idx = 4u * w + k;
+            if (idx >= lead && idx < total) f((v >> (8 * k)) & 0xffu);
+        }
+    }
+}
+
+constexpr uint32_t kDnaLongSide = 4096; // a longer y is scanned by a whole wavefront instead of one lane
+
+// One workgroup (4 wavefronts) per fill wavefront.  Pass 1, one THREAD per pair: the distinct symbols of x' (kept in
+// the order met -- the codes only have to agree between x and y), the sentinels, the byte-0 check; the verdict of
+// the whole fill wave is the AND over its pairs.  Pass 2, one wavefront per pair in turn, lanes across the bytes:
+// the image, coded or as bytes.  (The first version ran both passes pair by pair on one wavefront with five
+// reduction rounds per pair: 321 us for config 2 against 45 us of the plain pack; profiles/r02b.)
 __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ off, uint64_t base,
                                                    uint32_t *__restrict__ groups, uint32_t *__restrict__ waves, uint32_t n_fill_waves,
                                                    uint32_t n_pairs, uint32_t *__restrict__ img, uint32_t *__restrict__ flag)
 {
-    // per pack wavefront and slot (a fill wave has at most 64 groups x 2 pairs): {symbols of x, packed}, {flags, lx', ly'}
-    __shared__ uint32_t s_syms[4][128];
-    __shared__ uint32_t s_info[4][128];
+    // per pair of the fill wave (at most 64 groups x 2): {symbols of x', packed}, {verdict and lengths}
+    __shared__ uint32_t s_syms[128];
+    __shared__ uint32_t s_info[128];
+    __shared__ uint32_t s_not_dna;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    volatile uint32_t *syms_of = s_syms[wid], *info_of = s_info[wid];
-    const uint32_t n_pack_waves = gridDim.x * 4u;
-    for (uint32_t fw = blockIdx.x * 4u + wid; fw < n_fill_waves; fw += n_pack_waves) {
+    for (uint32_t fw = blockIdx.x; fw < n_fill_waves; fw += gridDim.x) {
         // SwWave: {first_group, n_groups | G << 16, steps, class word}
         const uint32_t first_group = waves[4 * (size_t)fw], n_groups = waves[4 * (size_t)fw + 1] & 0xffffu;
         const uint32_t gc = (waves[4 * (size_t)fw + 1] >> 16) * (waves[4 * (size_t)fw + 3] & 0xffffu); // columns of a lane group
         const uint32_t n_slots = n_groups * 2u;
-        bool all_dna = true;
-        // ---- pass 1: every pair of the wave: symbols of x, sentinels, the byte-0 check
-        for (uint32_t sl = 0; sl < n_slots; ++sl) {
+        if (threadIdx.x == 0) s_not_dna = 0;
+        __syncthreads();
+        // ---- pass 1
+        if (threadIdx.x < n_slots) {
+            const uint32_t sl = threadIdx.x;
             const uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
             const uint32_t h = sl & 1u, ll = rec[4 + h], out = rec[6 + h];
-            if (out >= n_pairs) { // vacant half: nothing to read, fits either kind of wave
-                if (lane == 0) info_of[sl] = 0x80000000u;
-                continue;
-            }
-            const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
-            const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
-            const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
-            const uint32_t xnl = lx && x[lx - 1] == '\n', ynl = ly && y[ly - 1] == '\n';
-            const uint32_t lxs = lx - xnl, lys = ly - ynl;
-            // distinct symbols of x', smallest first: repeatedly the smallest byte above the last one found
-            uint32_t syms = 0;
-            int nsym = 0;
-            bool bad = false, x_has_nl = false;
-            int last = -1;
-            for (int round = 0; round < 5; ++round) {
-                uint32_t mn = 256;
-                for (uint32_t i = lane; i < lxs; i += 64) {
-                    const uint32_t b = x[i];
-                    if (round == 0) {
-                        bad |= b == 0u;
-                        x_has_nl |= b == '\n';
-                    }
-                    if ((int)b > last && b < mn) mn = b;
-                }
+            uint32_t info = 0x80000000u, syms = 0; // vacant half: nothing to read, fits either kind of wave
+            if (out < n_pairs) {
+                const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
+                const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
+                const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
+                const uint32_t xnl = lx && x[lx - 1] == '\n', ynl = ly && y[ly - 1] == '\n';
+                const uint32_t lxs = lx - xnl, lys = ly - ynl;
+                uint32_t nsym = 0;
+                bool bad = false, x_has_nl = false, y_has_nl = false;
+                for_each_byte(x, lxs, [&](uint32_t b) {
+                    bad |= b == 0u;
+                    x_has_nl |= b == '\n';
+                    bool known = false;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-                if (mn == 256) break;
-                if (round < 4) syms |= mn << (8 * round);
-                ++nsym; // 5 = "more than four"
-                last = (int)mn;
+                    for (uint32_t k = 0; k < 4; ++k) known |= k < nsym && b == ((syms >> (8 * k)) & 0xffu);
+                    if (!known) {
+                        if (nsym < 4) syms |= b << (8 * nsym);
+                        nsym = min(nsym + 1u, 5u); // 5 = "more than four"
+                    }
+                });
+                const bool long_y = lys > kDnaLongSide;
+                if (!long_y)
+                    for_each_byte(y, lys, [&](uint32_t b) {
+                        bad |= b == 0u;
+                        y_has_nl |= b == '\n';
+                    });
+                if (bad) {
+                    atomicAdd(&flag[0], 1u);
+                    atomicMin(&flag[1], out);
+                }
+                const bool ok = nsym <= 4 && !(xnl && y_has_nl) && !(ynl && x_has_nl) && lx < 4096u;
+                if (!ok) s_not_dna = 1;
+                info = nsym | (xnl << 4) | (ynl << 5) | ((uint32_t)long_y << 6) | ((uint32_t)x_has_nl << 7);
             }
-            bool y_has_nl = false;
-            for (uint32_t i = lane; i < lys; i += 64) {
+            s_syms[sl] = syms;
+            s_info[sl] = info;
+        }
+        __syncthreads();
+        // long second sequences: their scan, a wavefront each
+        for (uint32_t sl = wid; sl < n_slots; sl += 4) {
+            const uint32_t info = s_info[sl];
+            if ((info & 0x80000000u) || !((info >> 6) & 1u)) continue;
+            const uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
+            const uint32_t h = sl & 1u, ll = rec[4 + h], out = rec[6 + h];
+            const uint32_t xsec = (ll >> 15) & 1u, ly = ll >> 16, ynl = (info >> 5) & 1u, xnl = (info >> 4) & 1u;
+            const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
+            bool bad = false, y_has_nl = false;
+            for (uint32_t i = lane; i < ly - ynl; i += 64) {
                 const uint32_t b = y[i];
                 bad |= b == 0u;
                 y_has_nl |= b == '\n';
@@ -161,16 +201,13 @@ __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ r
                 atomicAdd(&flag[0], 1u);
                 atomicMin(&flag[1], out);
             }
-            const bool ok = nsym <= 4 && !(xnl && __any(y_has_nl)) && !(ynl && __any(x_has_nl)) && lx < 4096u;
-            all_dna = all_dna && ok;
-            if (lane == 0) {
-                syms_of[sl] = syms;
-                info_of[sl] = (uint32_t)nsym | (xnl << 4) | (ynl << 5);
-            }
+            if (xnl && __any(y_has_nl) && lane == 0) s_not_dna = 1;
         }
+        __syncthreads();
+        const bool all_dna = s_not_dna == 0;
         // ---- pass 2: write the image, coded or as bytes
-        for (uint32_t sl = 0; sl < n_slots; ++sl) {
-            const uint32_t info = info_of[sl];
+        for (uint32_t sl = wid; sl < n_slots; sl += 4) {
+            const uint32_t info = s_info[sl];
             if (info & 0x80000000u) continue;
             uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
             const uint32_t h = sl & 1u, x_dw = rec[h], y_dw = rec[2 + h], ll = rec[4 + h], out = rec[6 + h];
@@ -178,7 +215,7 @@ __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ r
             const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
             const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
             if (all_dna) {
-                const uint32_t syms = syms_of[sl];
+                const uint32_t syms = s_syms[sl];
                 const int nsym = (int)(info & 0xfu);
                 const uint32_t xnl = (info >> 4) & 1u, ynl = (info >> 5) & 1u, lxs = lx - xnl, lys = ly - ynl;
                 const uint32_t lead = gc - lxs; // right-aligned: x'[k] sits in column lead + k
@@ -212,7 +249,8 @@ __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ r
                 copy_seq<false>(img + y_dw, (ly + 3u) >> 2, y, ly, nullptr, lane, bad);
             }
         }
-        if (all_dna && lane == 0) waves[4 * (size_t)fw + 3] |= 1u << 16;
+        if (all_dna && threadIdx.x == 0) waves[4 * (size_t)fw + 3] |= 1u << 16;
+        __syncthreads(); // the shared verdict is reset for the next fill wave
     }
 }
 
@@ -223,7 +261,7 @@ int agx_sw_pack_dna_launch(const uint8_t *raw, const uint64_t *off, uint64_t bas
 {
     if (n_waves == 0) return 0;
     static_assert(sizeof(SwWave) == 16 && sizeof(SwGroup2) == 32, "sw_pack_dna reads the records as words");
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n_waves + 3) / 4, (uint64_t)std::max(n_cu, 1) * 16u);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_waves, (uint64_t)std::max(n_cu, 1) * 32u);
     hipLaunchKernelGGL(sw_pack_dna, dim3(blocks), dim3(256), 0, s, raw, off, base, (uint32_t *)groups, (uint32_t *)waves, n_waves, n_pairs,
                        img, flag);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -181,6 +181,35 @@ def _as_regions(p):
     return out
 
 
+def test_packed_float_cell_variants(ctx, oracle):
+    """AGX_PHMM_F32_FMA runs the scaled cell (X, Y stored times the next row's 1 - Qg) unless a read has a
+    gap-continuation quality of Phred 0 ('!': 1 - Qg = 0, the scaling would divide by it) -- then the plain cell.  Both
+    against the oracle, with N in haplotypes and reads (an N haplotype column matches the neutral rows' empty base)."""
+    rng = np.random.default_rng(77)
+    acgtn = np.frombuffer(b"ACGTN", np.uint8)
+
+    def seq(n, p_n):
+        s = acgtn[rng.integers(0, 4, size=n)].copy()
+        s[rng.random(n) < p_n] = ord("N")
+        return s.tobytes()
+
+    def q(n, lo, hi):
+        return (rng.integers(lo, hi, size=n) + 33).astype(np.uint8).tobytes()
+
+    def batch(gcp_lo):
+        regions = []
+        for R, H, nr, nh in ((1, 86, 3, 2), (3, 86, 3, 3), (40, 120, 5, 4), (100, 300, 4, 4), (120, 33, 3, 1)):
+            reads = [(seq(R, 0.05), q(R, 2, 42), q(R, 20, 46), q(R, 20, 46), q(R, gcp_lo, 20)) for _ in range(nr)]
+            regions.append((reads, [seq(H + int(rng.integers(0, 9)), 0.3) for _ in range(nh)]))
+        return synth.phmm_from_regions(regions)
+
+    for gcp_lo in (1, 0):  # 0: some read carries '!'
+        b = batch(gcp_lo)
+        assert (b.q_gcp.min() == 33) == (gcp_lo == 0)
+        _, l_ref = oracle.phmm_batch(b, 0)
+        assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA), l_ref) <= 1e-6
+
+
 def test_degenerate_pairs(ctx, oracle):
     b = synth.phmm_from_regions([([(b"", b"", b"", b"", b""), (b"A", b"I", b"I", b"I", b"+")], [b"", b"A", b"ACGT"])])
     got = ctx.phmm_forward(b)

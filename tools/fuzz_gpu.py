@@ -90,6 +90,10 @@ while time.time() < t_end:
         # 1e-6 relative on the log10 likelihood or on the likelihood itself (BASELINE north star:
         # |dlog10| <= 1e-6 / ln 10) -- the first is meaningless where log10 L is close to 0 (reads of 1-2 bases)
         bad = (d > 1e-6 * np.abs(l_ref[m])) & (d > 1e-6 / np.log(10))
+        if bad.any():
+            Rs, Hs = b.pair_lengths()
+            idx = np.flatnonzero(m)[bad]
+            print("f32 family mismatch: pairs (index, R, H, got, ref):", [(int(k), int(Rs[k]), int(Hs[k]), float(got[k]), float(l_ref[k])) for k in idx[:12]], flush=True)
         assert not bad.any(), ("f32 family", prec, float(d[bad].max()), seed, n_ph)
     s3, _ = orc.phmm_batch(b, 3)
     dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR); dev.launch(); _, s = dev.results(); dev.close()
