@@ -4,6 +4,7 @@
 #include "agx_phmm.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <chrono>
@@ -191,7 +192,7 @@ struct agx_phmm_batch {
     bool gatk_prior = false;
     int64_t n_pairs = 0;
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
-    bool scaled = false;          // ... and its fill runs the scaled cell (no Phred-0 gap-continuation quality in the batch)
+    bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
     DevBuf img, sums, logs, lut, counter; // logs: float modes only (log10 taken on the device)
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
@@ -373,15 +374,23 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         agx_set_error("agx_phmm_batch_create: NULL track");
         return AGX_E_ARG;
     }
-    // packed float fill: its scaled cell divides by 1 - Qg (agx_phmm_pk_kernel.hip), so a gap-continuation quality of
-    // Phred 0 or below anywhere in the batch keeps the plain cell
-    std::atomic<bool> gcp_zero{false};
+    // packed float fill: its fast cell (agx_phmm_pk_kernel.hip) divides by 1 - Qg and codes the bases in two bits, so a
+    // gap-continuation quality of Phred 0 or below, a read base outside ACGTN or a haplotype base outside ACGT anywhere
+    // in the batch keeps the plain cell
+    std::atomic<bool> not_fast{false};
+    static const auto dna_table = [] {
+        std::array<uint8_t, 256> t{};
+        for (const char *p = "ACGT"; *p; ++p) t[(uint8_t)*p] = 3; // bit 0: allowed in a read, bit 1: in a haplotype
+        t[(uint8_t)'N'] = 1;
+        return t;
+    }();
     if (have_tracks) {
         agx_parallel_for((int64_t)n_reads, 2048, [&](int64_t ra, int64_t rz, int) {
             bool zero = false;
             for (int64_t r = ra; r < rz && packed && !probs; ++r)
-                for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k) zero |= d->q_gcp[k] <= (uint8_t)'!';
-            if (zero) gcp_zero.store(true, std::memory_order_relaxed);
+                for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k)
+                    zero |= d->q_gcp[k] <= (uint8_t)'!' || !(dna_table[d->read_bases[k]] & 1);
+            if (zero) not_fast.store(true, std::memory_order_relaxed);
             for (int64_t r = ra; r < rz; ++r) {
                 const uint64_t o = d->read_off[r];
                 const size_t R = (size_t)(d->read_off[r + 1] - o), trk = (R + 3) / 4;
@@ -407,6 +416,11 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 const size_t H = (size_t)(d->hap_off[h + 1] - o);
                 uint8_t *p = reinterpret_cast<uint8_t *>(img + hap_dw[(size_t)h]);
                 memcpy(p, d->hap_bases + o, H);
+                if (packed) {
+                    bool other = false;
+                    for (size_t k = 0; k < H; ++k) other |= !(dna_table[d->hap_bases[o + k]] & 2);
+                    if (other) not_fast.store(true, std::memory_order_relaxed);
+                }
                 memset(p + H, 0, hap_block_dw(H) * 4 - H);
             }
         });
@@ -706,7 +720,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->probs = probs;
     b->gatk_prior = gatk_prior;
     b->packed = packed;
-    b->scaled = packed && !gcp_zero.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
+    b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
     b->separate_rescue = packed;
     b->n_pairs = n_pairs;
     b->main.launches = pmain.launches;
@@ -900,7 +914,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         for (const ClassLaunch &cl : b->main.launches) {
             hipStream_t st = fan.stream(k++);
             if (b->packed) {
-                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->scaled, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->fast, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
                                                        (const PhTab *)b->main.tabs.p,
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
                                                        mis_for_f, (double *)b->sums.p, cl.lds, st);

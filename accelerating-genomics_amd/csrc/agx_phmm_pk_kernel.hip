@@ -12,12 +12,19 @@
 // v_mul/v_add_f32 reach 65 and v_fma_f32 42 (tools/valu_microbench.hip), and
 // tools/phmm_mix_microbench.hip measured the two cell loops at 0.17 vs 0.32 ps/cell.
 //
-// SCALED (the default; the host asks for it when no read has a gap-continuation quality of Phred 0, i.e. 1 - Qg > 0
-// everywhere): X and Y are stored multiplied by the NEXT row's gm = 1 - Qg, so the diagonal term gm * (X_d + Y_d) is a
-// bare sum and one multiplication per two cells is gone.  Every use of X and Y is a product with a row constant, so
-// the factor folds into the per-read table: X' = fma(M_up, Qi gm+, X'_up * (Qg gm+ / gm)), Y' = fma(Y'_left, Qg,
-// M_left * (Qd gm+)); gm+ = 1 behind the last row, so the final sum reads the true X; the row-0 state Y = init is
-// scaled by the first row's gm.  7 packed instructions + 2 compares + 2 selects per 2 cells.
+// FAST (the default; the host asks for it when (a) no read has a gap-continuation quality of Phred 0, i.e. 1 - Qg > 0
+// everywhere, (b) haplotypes hold only A, C, G, T and reads only A, C, G, T, N) changes two things:
+//   * X and Y are stored multiplied by the NEXT row's gm = 1 - Qg, so the diagonal term gm * (X_d + Y_d) is a bare
+//     sum and one multiplication per two cells is gone.  Every use of X and Y is a product with a row constant, so the
+//     factor folds into the per-read table: X' = fma(M_up, Qi gm+, X'_up * (Qg gm+ / gm)), Y' = fma(Y'_left, Qg,
+//     M_left * (Qd gm+)); gm+ = 1 behind the last row, so the final sum reads the true X; the row-0 state Y = init
+//     is scaled by the first row's gm.
+//   * the match test is a table lookup: a row carries T, the byte 0x3f at the position of its base's two-bit code
+//     ((b >> 1) & 3; everywhere for N), each column one v_perm_b32 selector {0x0c, 0x0c, 4 + code_b, code_a}.
+//     v_perm_b32(0, T, sel) is 0x3f000000 = 0.5f where haplotype a matches, v_perm_b32(T', 0, sel) with
+//     T' = (T & 0x01010101) << 7 is 0x00800000 = 2^-126 where b does, and prior = fma({0.5, 2^-126} or 0,
+//     {2 (pm - pq), 2^126 (pm - pq)}, pq) -- three instructions where two compares and two selects stood.
+// = 10 packed/perm instructions per 2 cells against 12.
 //
 // Numerics: float with the initial constant FLT_MAX/16 like AGX_PHMM_F32, but contracted -- not
 // bit-identical to the oracle's float restatement; the bar is BASELINE config 3's 1e-6 relative on
@@ -50,7 +57,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 
 // ROW16: every wave of the launch has groups of exactly 16 lanes (uniform batches such as H = 300 in 16 x 19):
 // the groups coincide with the DPP rows, and the row shift's zero fill is the column-0 boundary.
-template <int C, bool ROW16, bool SCALED>
+template <int C, bool ROW16, bool FAST>
 __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                   uint32_t n_waves, const float *__restrict__ lut,
@@ -84,7 +91,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     // operations p()/mm() prescribe (:111-117), done once per row here instead of once per lane and
     // step; a lane fetches its row with two ds_read_b128 from one address.  Neutral rows (before
     // the read and behind it): priors irrelevant, mm = 1, 1-Qg = 0, Qi = Qd = 0, Qg = 1.
-    // SCALED: {1-Qr, mismatch prior, 1-(Qi+Qd), Qi gm+ | Qg gm+ / gm, Qd gm+, Qg, base}, gm of a row before the read =
+    // FAST: {mismatch prior pq, 2 (pm - pq), 1-(Qi+Qd), Qi gm+ | Qg gm+ / gm, Qd gm+, Qg, T}, gm of a row before the read =
     // the first row's, behind it = 1, and both priors of a neutral row 0 (neutral rows then keep the scaled state as it is).
     const uint32_t rows = w.steps + (uint32_t)G - 1u;
     const size_t tab_bytes = ph_pk_tab_bytes(rows);
@@ -107,7 +114,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             }
             const float pm = 1 - vr;                          // p(): match or N
             const float pq = c == (uint32_t)'N' ? pm : vm;    //      mismatch
-            if constexpr (SCALED) {
+            if constexpr (FAST) {
                 auto gm_of = [&](int k) -> float { // 1 - Qg of read row k, extended to both sides
                     if (k >= (int)tb.R) return 1.f;
                     return 1 - lut[rp[4 * trk + (k < 0 ? 0 : k)]];
@@ -116,8 +123,9 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
                 // (a neutral row's priors are BOTH zero here: the plain cell's neutral rows keep M = 0 through gm = 0,
                 // which this cell no longer multiplies with -- a haplotype N would match the row and pick 1 - Qr = 1)
                 const bool real = i >= 0 && i < (int)tb.R;
-                tr[2 * r] = float4{real ? pm : 0.f, real ? pq : 0.f, 1 - (vi + vd), (float)((double)vi * gp)};
-                tr[2 * r + 1] = float4{(float)((double)vg * gp / g), (float)((double)vd * gp), vg, __uint_as_float(c)};
+                const uint32_t tbl = !real ? 0u : c == (uint32_t)'N' ? 0x3f3f3f3fu : 0x3fu << (8u * ((c >> 1) & 3u));
+                tr[2 * r] = float4{real ? pq : 0.f, real ? 2 * (pm - pq) : 0.f, 1 - (vi + vd), (float)((double)vi * gp)};
+                tr[2 * r + 1] = float4{(float)((double)vg * gp / g), (float)((double)vd * gp), vg, __uint_as_float(tbl)};
             } else {
                 tr[2 * r] = float4{pm, pq, 1 - (vi + vd), 1 - vg}; // mm() (:115-117)
                 tr[2 * r + 1] = float4{vi, vd, vg, __uint_as_float(c)};
@@ -129,7 +137,8 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     const uint32_t tabi = g.R_tab >> 16;
     const float4 *trow = reinterpret_cast<const float4 *>(lds + tabi * tab_bytes) + 2 * (G - 1 - gl);
 
-    // this lane's C bases of both haplotypes, one register per column: a | b << 16
+    // this lane's C bases of both haplotypes, one register per column: a | b << 16;  FAST: the v_perm_b32 selector
+    // {0x0c, 0x0c, 4 + code_b, code_a}, 0x0c (the constant 0: matches nothing) for the padding behind a haplotype
     uint32_t hq[C];
     unsigned long long na = 0, nb = 0; // haplotype 'N' matches every read base (:111-113); rare
     {
@@ -148,7 +157,10 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             for (int i = 0; i < 4; ++i)
                 if (4 * k + i < C) {
                     const uint32_t ca = (a >> (8 * i)) & 0xffu, cb = (b >> (8 * i)) & 0xffu;
-                    hq[4 * k + i] = ca | (cb << 16);
+                    if constexpr (FAST)
+                        hq[4 * k + i] = 0x0c0cu | ((cb ? 4u + ((cb >> 1) & 3u) : 0x0cu) << 16) | ((ca ? (ca >> 1) & 3u : 0x0cu) << 24);
+                    else
+                        hq[4 * k + i] = ca | (cb << 16);
                     na |= (ca == (uint32_t)'N' ? 1ull : 0ull) << (4 * k + i);
                     nb |= (cb == (uint32_t)'N' ? 1ull : 0ull) << (4 * k + i);
                 }
@@ -156,7 +168,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     }
 
     f2 init = f2{g.init32[0], g.init32[1]};
-    if constexpr (SCALED) { // row 0's Y as the first read row consumes it: times that row's gm
+    if constexpr (FAST) { // row 0's Y as the first read row consumes it: times that row's gm
         if (active) {
             const PhTab tb = tabs[w.first_tab + tabi];
             const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
@@ -183,10 +195,12 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             const float4 ra = trow[2 * t], rb = trow[2 * t + 1];
             const float pm = ra.x, pq = ra.y;
             const uint32_t rc = __float_as_uint(rb.w);
-            // plain: {.., mm, gm | Qi, Qd, Qg};  SCALED: {.., mm, Qi gm+ | Qg gm+ / gm, Qd gm+, Qg}
+            // plain: {pm, pq, mm, gm | Qi, Qd, Qg, base};  FAST: {pq, 2 (pm - pq), mm, Qi gm+ | Qg gm+ / gm, Qd gm+, Qg, T}
             const f2 mm = splat(ra.z), gm = splat(ra.w);
-            const f2 qi = splat(SCALED ? ra.w : rb.x), qd = splat(rb.y), qg = splat(rb.z);
-            const f2 qx = splat(SCALED ? rb.x : rb.z); // what X_up is multiplied with
+            const f2 qi = splat(FAST ? ra.w : rb.x), qd = splat(rb.y), qg = splat(rb.z);
+            const f2 qx = splat(FAST ? rb.x : rb.z); // what X_up is multiplied with
+            const f2 pq2 = splat(ra.x), dp2 = f2{ra.y, ra.y * 0x1p125f}; // FAST: prior = fma(flag, dp2, pq2)
+            const uint32_t t80 = (rc & 0x01010101u) << 7;
 
             f2 lM, lX, lY; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
             if constexpr (ROW16) {
@@ -210,17 +224,23 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             // pass A, right to left: M and X in place
 #pragma unroll
             for (int j = C - 1; j >= 0; --j) {
-                bool ma = (hq[j] & 0xffffu) == rc, mb = (hq[j] >> 16) == rc;
-                if constexpr (HAPN) {
-                    ma = ma || ((na >> j) & 1ull);
-                    mb = mb || ((nb >> j) & 1ull);
+                f2 prior;
+                if constexpr (FAST) {
+                    const f2 flag = f2{__uint_as_float(__builtin_amdgcn_perm(0u, rc, hq[j])), __uint_as_float(__builtin_amdgcn_perm(t80, 0u, hq[j]))};
+                    prior = fma2(flag, dp2, pq2);
+                } else {
+                    bool ma = (hq[j] & 0xffffu) == rc, mb = (hq[j] >> 16) == rc;
+                    if constexpr (HAPN) {
+                        ma = ma || ((na >> j) & 1ull);
+                        mb = mb || ((nb >> j) & 1ull);
+                    }
+                    prior = f2{ma ? pm : pq, mb ? pm : pq};
                 }
-                const f2 prior = f2{ma ? pm : pq, mb ? pm : pq};
                 const f2 dM = j ? M[j > 0 ? j - 1 : 0] : dM0;
                 const f2 dX = j ? X[j > 0 ? j - 1 : 0] : dX0;
                 const f2 dY = j ? Y[j > 0 ? j - 1 : 0] : dY0;
                 const f2 x = fma2(M[j], qi, X[j] * qx);
-                const f2 m = prior * fma2(mm, dM, SCALED ? dX + dY : gm * (dX + dY));
+                const f2 m = prior * fma2(mm, dM, FAST ? dX + dY : gm * (dX + dY));
                 X[j] = x;
                 M[j] = m;
             }
@@ -269,7 +289,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             }
         }
     };
-    if (__any((na | nb) != 0))
+    if (!FAST && __any((na | nb) != 0))
         fill(std::true_type{});
     else
         fill(std::false_type{});
@@ -287,47 +307,47 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     }
 }
 
-template <int C, bool ROW16, bool SCALED>
+template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                    const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                    uint32_t n_waves, const float *__restrict__ lut,
                                                    const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_fill_pk_body<C, ROW16, SCALED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
 // Same fill asked to fit three waves per SIMD (168 VGPRs).  Width 19 -- the tiling of H = 300 -- needs
 // 172 left alone and drops to two waves; the two spilled values are touched once per row.
-template <int C, bool ROW16, bool SCALED>
+template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 phmm_fill_pk_w3(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
                 const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
                 const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_fill_pk_body<C, ROW16, SCALED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
 // ... and two waves per SIMD (256 VGPRs) for widths 31 and 32 (H = 500 in 16 x 32), 257 left alone.
-template <int C, bool ROW16, bool SCALED>
+template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_pk_w2(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
                 const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
                 const float *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_fill_pk_body<C, ROW16, SCALED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
-template <int C, bool ROW16, bool SCALED>
+template <int C, bool ROW16, bool FAST>
 int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
            const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
     void (*k)(const uint32_t *, const PhGroup2 *, const PhTab *, const PhWave *, uint32_t, const float *, const float *, double *);
     if constexpr (C == kPkThreeWaveWidth)
-        k = phmm_fill_pk_w3<C, ROW16, SCALED>;
+        k = phmm_fill_pk_w3<C, ROW16, FAST>;
     else if constexpr (C > 30)
-        k = phmm_fill_pk_w2<C, ROW16, SCALED>;
+        k = phmm_fill_pk_w2<C, ROW16, FAST>;
     else
-        k = phmm_fill_pk<C, ROW16, SCALED>;
+        k = phmm_fill_pk<C, ROW16, FAST>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
@@ -339,7 +359,7 @@ int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const
 
 } // namespace
 
-int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool scaled, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
+int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              size_t lds_bytes, hipStream_t s)
 {
@@ -347,9 +367,9 @@ int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool scaled,
     switch (cols_per_lane) {
 #define AGX_PH_PK_CASE(CC) \
     case CC: \
-        return all_groups_16 ? (scaled ? launch<CC, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
+        return all_groups_16 ? (fast ? launch<CC, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
                                        : launch<CC, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s)) \
-                             : (scaled ? launch<CC, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
+                             : (fast ? launch<CC, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
                                        : launch<CC, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s));
         AGX_PH_FOR_EACH_PK_CLASS(AGX_PH_PK_CASE)
 #undef AGX_PH_PK_CASE

@@ -182,9 +182,10 @@ def _as_regions(p):
 
 
 def test_packed_float_cell_variants(ctx, oracle):
-    """AGX_PHMM_F32_FMA runs the scaled cell (X, Y stored times the next row's 1 - Qg) unless a read has a
-    gap-continuation quality of Phred 0 ('!': 1 - Qg = 0, the scaling would divide by it) -- then the plain cell.  Both
-    against the oracle, with N in haplotypes and reads (an N haplotype column matches the neutral rows' empty base)."""
+    """AGX_PHMM_F32_FMA runs the fast cell (X, Y stored times the next row's 1 - Qg; bases as two-bit codes, the match a
+    table lookup) on plain DNA -- haplotypes of A, C, G, T, reads of A, C, G, T, N -- unless a read has a gap-continuation
+    quality of Phred 0 ('!': 1 - Qg = 0, the scaling would divide by it); everything else takes the plain cell.  All
+    three kinds of batch against the oracle: 1e-6 relative on log10 L, or on L itself where log10 L is near 0."""
     rng = np.random.default_rng(77)
     acgtn = np.frombuffer(b"ACGTN", np.uint8)
 
@@ -196,18 +197,22 @@ def test_packed_float_cell_variants(ctx, oracle):
     def q(n, lo, hi):
         return (rng.integers(lo, hi, size=n) + 33).astype(np.uint8).tobytes()
 
-    def batch(gcp_lo):
+    def batch(gcp_lo, hap_n):
         regions = []
         for R, H, nr, nh in ((1, 86, 3, 2), (3, 86, 3, 3), (40, 120, 5, 4), (100, 300, 4, 4), (120, 33, 3, 1)):
             reads = [(seq(R, 0.05), q(R, 2, 42), q(R, 20, 46), q(R, 20, 46), q(R, gcp_lo, 20)) for _ in range(nr)]
-            regions.append((reads, [seq(H + int(rng.integers(0, 9)), 0.3) for _ in range(nh)]))
+            regions.append((reads, [seq(H + int(rng.integers(0, 9)), hap_n) for _ in range(nh)]))
         return synth.phmm_from_regions(regions)
 
-    for gcp_lo in (1, 0):  # 0: some read carries '!'
-        b = batch(gcp_lo)
-        assert (b.q_gcp.min() == 33) == (gcp_lo == 0)
+    for gcp_lo, hap_n in ((1, 0.0), (0, 0.0), (1, 0.3)):  # fast; plain because of '!'; plain because of N haplotypes
+        b = batch(gcp_lo, hap_n)
+        assert (b.q_gcp.min() == 33) == (gcp_lo == 0) and (bytes(b.hap_bases).count(b"N") > 0) == (hap_n > 0)
         _, l_ref = oracle.phmm_batch(b, 0)
-        assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA), l_ref) <= 1e-6
+        got = ctx.phmm_forward(b, agx.PHMM_F32_FMA)
+        ok = np.isfinite(l_ref)
+        assert np.array_equal(np.isfinite(got), ok)
+        d = np.abs(got[ok] - l_ref[ok])
+        assert not ((d > 1e-6 * np.abs(l_ref[ok])) & (d > 1e-6 / np.log(10))).any()
 
 
 def test_degenerate_pairs(ctx, oracle):
