@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # Measured wave64 issue cost on this chip (tools/valu_microbench2.hip, profiles/r02_valu_microbench2.log): every
 # v_pk_* instruction 4.2 cycles per SIMD; v_add/sub/xor_u32 2.4 in a pure stream but 4.2 beside packed ones
 # (profiles/r02_valu_microbench3.log), so every instruction of the cell is priced at the packed rate.
-VALU_PACKED, VALU_SLOW = 37.5e12, 38e12  # lane-instructions / s
+VALU_PACKED = 37.5e12  # lane-instructions / s
 WINDOW = "kernel launch -> results resident in (page-locked) host memory, inputs resident in HBM (hipvers.cpp:475-483)"
 
 
@@ -397,8 +397,8 @@ def main():
         "roofline": roof(sw.algorithmic_bytes(), sw_t["launch_ms"], "sw_fill"),
         "sw": {"waves": sw_info.n_waves, "launches_per_step": sw_info.n_launches,
                "useful_cell_fraction": sw_info.cells / max(1, sw_info.padded_cells),
-               "valu": {"ops_per_cell": "10.5 instructions per 2 cells: 4.5 packed (v_pk_maximum3_f16 x2.5, v_pk_max_u16, v_pk_min_u16) + 6 32-bit add/sub/xor",
-                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (10.5 / 2 / VALU_PACKED) / (sw_t["launch_ms"] * 1e-3)},
+               "valu": {"ops_per_cell": "7.5 instructions per 2 cells (DNA-coded rising-offset cell): v_pk_maximum3_f16 x2.5, v_pk_max_u16, v_perm_b32, v_add3_u32, v_sub_u32 x2",
+                        "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (7.5 / 2 / VALU_PACKED) / (sw_t["launch_ms"] * 1e-3)},
                "score_checksum": sw_sum},
         "sw_int32": dict(i32_leg, metric="config 2 through the int32 kernel (one pair per lane group, AGX_SW_KERNEL_INT32)", unit="GCUPS",
                          scores_identical_to_packed=i32_same, useful_cell_fraction=i32_info.cells / max(1, i32_info.padded_cells),
@@ -409,8 +409,8 @@ def main():
                         waves=ph_info.n_waves, launches_per_step=ph_info.n_launches,
                         useful_cell_fraction=ph_info.cells / max(1, ph_info.padded_cells),
                         roofline=roof(ph.algorithmic_bytes(), ph_t["launch_ms"], "phmm_fill"),
-                        valu={"ops_per_cell": "8 packed fp32 instructions + 2 compares + 2 selects per 2 cells",
-                              "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (4 / VALU_PACKED + 2 / VALU_SLOW) / (ph_t["launch_ms"] * 1e-3)},
+                        valu={"ops_per_cell": "10 instructions per 2 cells (fast cell): v_pk_fma_f32 x4, v_pk_mul_f32 x3, v_pk_add_f32, v_perm_b32 x2",
+                              "frac_of_instruction_mix_ceiling": ph_info.padded_cells * (10 / 2 / VALU_PACKED) / (ph_t["launch_ms"] * 1e-3)},
                         log10_checksum=ph_sum),
     }
     if extra:
