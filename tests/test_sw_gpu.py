@@ -276,3 +276,47 @@ def test_matrix_with_no_negative_entry_and_empty_sides(ctx, oracle):
     with pytest.raises(agx.AgxError) as e:
         _scores(ctx, synth.sw_from_seqs([b"ABC", b"AB"]), m)
     assert e.value.code == agx.E_SYMBOL
+
+
+def test_all_four_cells_of_the_biased_fill(ctx, oracle):
+    """The default SW kernel picks its cell per batch and per wavefront (agx_sw_pk2_kernel.hip): DNA-coded or general
+    (decided on the device: at most four symbols per shorter sequence, sentinels only at the very end) x rising offsets
+    or plain (decided on the host: rows up to about 27 000).  One batch per combination, each with sentinel variants
+    (both, one, none), a newline inside a sequence, and a fifth symbol, against the oracle."""
+    rng = np.random.default_rng(4242)
+    acgt, prot = np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+
+    def seq(n, alpha):
+        return alpha[rng.integers(0, alpha.size, size=n)].tobytes()
+
+    def related(a, alpha):
+        b = bytearray(a)
+        for _ in range(max(1, len(b) // 40)):
+            pos = int(rng.integers(0, len(b)))
+            b[pos : pos + int(rng.integers(0, 3))] = seq(int(rng.integers(0, 3)), alpha)
+        return bytes(b)
+
+    def batch(alpha, long_rows):
+        seqs = []
+        for k in range(160):
+            lx = int(rng.integers(1, 300))
+            ly = int(rng.integers(1, 400))
+            a = seq(lx, alpha)
+            b = related(a, alpha) + seq(ly, alpha) if k % 3 else seq(ly, alpha)
+            nl = k % 4  # both, first only, second only, none
+            a += b"\n" if nl in (0, 1) else b""
+            b += b"\n" if nl in (0, 2) else b""
+            if k % 17 == 5:
+                b = b[: len(b) // 2] + b"\n" + b[len(b) // 2 :]  # a newline INSIDE: the sentinel may align with it
+            if k % 19 == 7:
+                a = a[:1] + b"N" + a[1:]  # a fifth symbol in some pairs
+            seqs += [a, b]
+        if long_rows:  # one pair beyond the rising cell's range moves the whole batch to the plain cell
+            a = seq(200, alpha)
+            seqs += [a + b"\n", seq(15000, alpha) + a + seq(15000, alpha) + b"\n"]
+        return synth.sw_from_seqs(seqs)
+
+    for alpha in (acgt, prot):
+        for long_rows in (False, True):
+            b = batch(alpha, long_rows)
+            assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b)), (alpha.size, long_rows)
