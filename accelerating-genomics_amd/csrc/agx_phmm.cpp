@@ -969,11 +969,15 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     // the reference's output), by the device for the float modes (agx_phmm_finish_kernel.hip)
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool want_sums = raw_sum != nullptr || !f32;
-    char *at = (char *)b->out_stage.p; // [logs (float modes)][sums (when wanted)][rescue counter]
+    char *at = (char *)b->out_stage.p; // [rescue counter][logs (float modes)][sums (when wanted)]
+    unsigned long long *host_counter = (unsigned long long *)at; // written by the finish kernel itself (float modes only:
+    *host_counter = 0;                                           // the double modes have no rescue pass)
+    at += sizeof(double);
     double *s = nullptr, *dev_logs = nullptr;
     hipStream_t st = b->ctx->stream;
     if (f32 && b->n_pairs) {
-        if (agx_phmm_finish_launch((const double *)b->sums.p, (double *)b->logs.p, (uint32_t)b->n_pairs, c64, c32, st)) {
+        if (agx_phmm_finish_launch((const double *)b->sums.p, (double *)b->logs.p, (uint32_t)b->n_pairs, c64, c32,
+                                   (const unsigned long long *)b->counter.p, host_counter, st)) {
             agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }
@@ -986,11 +990,8 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
         if (b->n_pairs) AGX_HIP(hipMemcpyAsync(s, b->sums.p, sum_bytes, hipMemcpyDeviceToHost, st));
         at += sum_bytes;
     }
-    AGX_HIP(hipMemcpyAsync(at, b->counter.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     AGX_HIP(hipStreamSynchronize(st));
-    unsigned long long nres = 0;
-    memcpy(&nres, at, sizeof nres);
-    b->info.n_rescued = (int64_t)nres;
+    b->info.n_rescued = (int64_t)*(volatile unsigned long long *)host_counter;
     if (f32) {
         if (b->n_pairs && dev_logs != log10_lik) memcpy(log10_lik, dev_logs, sum_bytes);
     } else

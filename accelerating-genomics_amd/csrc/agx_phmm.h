@@ -100,7 +100,8 @@ int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, con
                            uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 // float modes: log10(sum) - log10(C) per pair on the device (a negated sum = recomputed in double, scaled by DBL_MAX/16)
-int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32, hipStream_t s);
+int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32,
+                           const unsigned long long *n_rescued, unsigned long long *n_rescued_host, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
                           const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                           double rescue_below,

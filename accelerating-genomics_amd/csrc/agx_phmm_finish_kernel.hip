@@ -11,9 +11,13 @@
 namespace {
 
 __global__ void __launch_bounds__(256) phmm_finish_f32(const double *__restrict__ sums, double *__restrict__ logs, uint32_t n,
-                                                       double log_c64, double log_c32)
+                                                       double log_c64, double log_c32, const unsigned long long *__restrict__ n_rescued,
+                                                       unsigned long long *__restrict__ n_rescued_host)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    // the rescue counter goes to page-locked host memory from here: a D2H copy of its own for eight bytes cost
+    // about as much as the copy of the results
+    if (k == 0) *n_rescued_host = *n_rescued;
     if (k >= n) return;
     double v = sums[k];
     double c = log_c32;
@@ -26,9 +30,10 @@ __global__ void __launch_bounds__(256) phmm_finish_f32(const double *__restrict_
 
 } // namespace
 
-int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32, hipStream_t s)
+int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32,
+                           const unsigned long long *n_rescued, unsigned long long *n_rescued_host, hipStream_t s)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(phmm_finish_f32, dim3((n + 255) / 256), dim3(256), 0, s, sums, logs, n, log_c64, log_c32);
+    hipLaunchKernelGGL(phmm_finish_f32, dim3((n + 255) / 256), dim3(256), 0, s, sums, logs, n, log_c64, log_c32, n_rescued, n_rescued_host);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
