@@ -119,9 +119,9 @@ __device__ __forceinline__ void for_each_byte(const uint8_t *p, uint32_t n, F f)
 
 constexpr uint32_t kDnaLongSide = 4096; // a longer y is scanned by a whole wavefront instead of one lane
 
-// One workgroup (4 wavefronts) per fill wavefront.  Pass 1, one THREAD per pair: the distinct symbols of x' (kept in
-// the order met -- the codes only have to agree between x and y), the sentinels, the byte-0 check; the verdict of
-// the whole fill wave is the AND over its pairs.  Pass 2, one wavefront per pair in turn, lanes across the bytes:
+// One workgroup (4 wavefronts) per fill wavefront.  Pass 1, two THREADS per pair, one on each sequence: the distinct
+// symbols of x' (kept in the order met -- the codes only have to agree between x and y), the sentinels, the byte-0
+// check; the verdict of the whole fill wave is the AND over its pairs.  Pass 2, one wavefront per pair in turn, lanes across the bytes:
 // the image, coded or as bytes.  (The first version ran both passes pair by pair on one wavefront with five
 // reduction rounds per pair: 321 us for config 2 against 45 us of the plain pack; profiles/r02b.)
 __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ raw, const uint64_t *__restrict__ off, uint64_t base,
@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ r
     // per pair of the fill wave (at most 64 groups x 2): {symbols of x', packed}, {verdict and lengths}
     __shared__ uint32_t s_syms[128];
     __shared__ uint32_t s_info[128];
+    __shared__ uint32_t s_yinfo[128];
     __shared__ uint32_t s_not_dna;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     for (uint32_t fw = blockIdx.x; fw < n_fill_waves; fw += gridDim.x) {
@@ -140,47 +141,65 @@ __global__ void __launch_bounds__(256) sw_pack_dna(const uint8_t *__restrict__ r
         const uint32_t n_slots = n_groups * 2u;
         if (threadIdx.x == 0) s_not_dna = 0;
         __syncthreads();
-        // ---- pass 1
-        if (threadIdx.x < n_slots) {
-            const uint32_t sl = threadIdx.x;
-            const uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
-            const uint32_t h = sl & 1u, ll = rec[4 + h], out = rec[6 + h];
-            uint32_t info = 0x80000000u, syms = 0; // vacant half: nothing to read, fits either kind of wave
-            if (out < n_pairs) {
-                const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
-                const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
-                const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
-                const uint32_t xnl = lx && x[lx - 1] == '\n', ynl = ly && y[ly - 1] == '\n';
-                const uint32_t lxs = lx - xnl, lys = ly - ynl;
-                uint32_t nsym = 0;
-                bool bad = false, x_has_nl = false, y_has_nl = false;
-                for_each_byte(x, lxs, [&](uint32_t b) {
-                    bad |= b == 0u;
-                    x_has_nl |= b == '\n';
-                    bool known = false;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) known |= k < nsym && b == ((syms >> (8 * k)) & 0xffu);
-                    if (!known) {
-                        if (nsym < 4) syms |= b << (8 * nsym);
-                        nsym = min(nsym + 1u, 5u); // 5 = "more than four"
+        // ---- pass 1: two threads per pair, one on each sequence
+        {
+            const uint32_t sl = threadIdx.x >> 1, which = threadIdx.x & 1u;
+            if (sl < n_slots) {
+                const uint32_t *rec = groups + (size_t)(first_group + sl / 2u) * 8u;
+                const uint32_t h = sl & 1u, ll = rec[4 + h], out = rec[6 + h];
+                if (out >= n_pairs) { // vacant half: nothing to read, fits either kind of wave
+                    if (which == 0) {
+                        s_syms[sl] = 0;
+                        s_info[sl] = 0x80000000u;
+                    } else
+                        s_yinfo[sl] = 0;
+                } else {
+                    const uint32_t lx = ll & 0x7fffu, xsec = (ll >> 15) & 1u, ly = ll >> 16;
+                    const uint8_t *x = raw + (off[2 * (size_t)out + xsec] - base);
+                    const uint8_t *y = raw + (off[2 * (size_t)out + (xsec ^ 1u)] - base);
+                    const uint32_t xnl = lx && x[lx - 1] == '\n', ynl = ly && y[ly - 1] == '\n';
+                    const uint32_t lxs = lx - xnl, lys = ly - ynl;
+                    bool bad = false, has_nl = false;
+                    if (which == 0) {
+                        uint32_t s0 = 0x100, s1 = 0x100, s2 = 0x100, s3 = 0x100, nsym = 0; // 0x100: no byte
+                        for_each_byte(x, lxs, [&](uint32_t b) {
+                            bad |= b == 0u;
+                            has_nl |= b == '\n';
+                            if (b != s0 && b != s1 && b != s2 && b != s3) {
+                                if (nsym == 0) s0 = b;
+                                if (nsym == 1) s1 = b;
+                                if (nsym == 2) s2 = b;
+                                if (nsym == 3) s3 = b;
+                                nsym = min(nsym + 1u, 5u); // 5 = "more than four"
+                            }
+                        });
+                        s_syms[sl] = (s0 & 0xffu) | ((s1 & 0xffu) << 8) | ((s2 & 0xffu) << 16) | ((s3 & 0xffu) << 24);
+                        s_info[sl] = nsym | (xnl << 4) | (ynl << 5) | ((uint32_t)(lys > kDnaLongSide) << 6) | ((uint32_t)has_nl << 7) |
+                                     ((uint32_t)bad << 8) | ((uint32_t)(lx >= 4096u) << 9);
+                    } else {
+                        if (lys <= kDnaLongSide)
+                            for_each_byte(y, lys, [&](uint32_t b) {
+                                bad |= b == 0u;
+                                has_nl |= b == '\n';
+                            });
+                        s_yinfo[sl] = (uint32_t)has_nl | ((uint32_t)bad << 1);
                     }
-                });
-                const bool long_y = lys > kDnaLongSide;
-                if (!long_y)
-                    for_each_byte(y, lys, [&](uint32_t b) {
-                        bad |= b == 0u;
-                        y_has_nl |= b == '\n';
-                    });
-                if (bad) {
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < n_slots) {
+            const uint32_t sl = threadIdx.x, info = s_info[sl], yinfo = s_yinfo[sl];
+            if (!(info & 0x80000000u)) {
+                const uint32_t nsym = info & 0xfu, xnl = (info >> 4) & 1u, ynl = (info >> 5) & 1u, x_has_nl = (info >> 7) & 1u;
+                if (((info >> 8) | (yinfo >> 1)) & 1u) {
+                    const uint32_t out = groups[(size_t)(first_group + sl / 2u) * 8u + 6 + (sl & 1u)];
                     atomicAdd(&flag[0], 1u);
                     atomicMin(&flag[1], out);
                 }
-                const bool ok = nsym <= 4 && !(xnl && y_has_nl) && !(ynl && x_has_nl) && lx < 4096u;
+                const bool ok = nsym <= 4 && !(xnl && (yinfo & 1u)) && !(ynl && x_has_nl) && !((info >> 9) & 1u);
                 if (!ok) s_not_dna = 1;
-                info = nsym | (xnl << 4) | (ynl << 5) | ((uint32_t)long_y << 6) | ((uint32_t)x_has_nl << 7);
             }
-            s_syms[sl] = syms;
-            s_info[sl] = info;
         }
         __syncthreads();
         // long second sequences: their scan, a wavefront each
