@@ -721,6 +721,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->gatk_prior = gatk_prior;
     b->packed = packed;
     b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
+    // the code objects this batch will launch from, loaded now rather than inside its first launch
+    if (ctx) {
+        if (packed) agx_phmm_pk_preload();
+        agx_phmm_scalar_preload();
+        if (precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA) agx_phmm_finish_preload();
+    }
     b->separate_rescue = packed;
     b->n_pairs = n_pairs;
     b->main.launches = pmain.launches;

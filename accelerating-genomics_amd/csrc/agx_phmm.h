@@ -100,6 +100,9 @@ int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, con
                            uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 // float modes: log10(sum) - log10(C) per pair on the device (a negated sum = recomputed in double, scaled by DBL_MAX/16)
+void agx_phmm_pk_preload();
+void agx_phmm_scalar_preload();
+void agx_phmm_finish_preload();
 int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32,
                            const unsigned long long *n_rescued, unsigned long long *n_rescued_host, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,

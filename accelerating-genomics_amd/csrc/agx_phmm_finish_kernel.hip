@@ -37,3 +37,11 @@ int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double 
     hipLaunchKernelGGL(phmm_finish_f32, dim3((n + 255) / 256), dim3(256), 0, s, sums, logs, n, log_c64, log_c32, n_rescued, n_rescued_host);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// Loads this file's code object now: the first launch of a kernel otherwise pays for it (1-2 ms in a fresh process --
+// inside hipvers' launch -> scores window).  Called when a batch that will use these kernels is created.
+void agx_phmm_finish_preload()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_finish_f32));
+}

@@ -369,3 +369,11 @@ int agx_phmm_launch_class(int mode, int cols_per_lane, bool all_groups_16, const
     }
 #undef AGX_PH_CASE
 }
+
+// Loads this file's code object now: the first launch of a kernel otherwise pays for it (1-2 ms in a fresh process --
+// inside hipvers' launch -> scores window).  Called when a batch that will use these kernels is created.
+void agx_phmm_scalar_preload()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_w2<double, 32, false, false, false, true>));
+}

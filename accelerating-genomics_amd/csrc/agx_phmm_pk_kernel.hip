@@ -376,3 +376,11 @@ int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, c
     default: return -2;
     }
 }
+
+// Loads this file's code object now: the first launch of a kernel otherwise pays for it (1-2 ms in a fresh process --
+// inside hipvers' launch -> scores window).  Called when a batch that will use these kernels is created.
+void agx_phmm_pk_preload()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_pk_w3<kPkThreeWaveWidth, true, true>));
+}

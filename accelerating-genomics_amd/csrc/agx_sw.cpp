@@ -527,6 +527,11 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     b->n_pairs = n_pairs;
     b->family = family;
     b->rising = rising;
+    if (ctx) { // the code objects this batch will launch from, loaded now rather than inside its first launch
+        agx_sw_pack_preload();
+        if (family == 2) agx_sw_pk2_preload();
+        if (family == 0 && !matrix) agx_sw_i32_preload();
+    }
     b->matrix = matrix != nullptr;
     b->prm = prm;
 

@@ -302,3 +302,11 @@ int agx_sw_pack_launch(bool matrix, int slots, const uint8_t *raw, const uint64_
         hipLaunchKernelGGL((sw_pack<false, 1>), dim3(blocks), dim3(256), 0, s, raw, off, base, g, n_groups, n_pairs, img, code, flag);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// Loads this file's code object now: the first launch of a kernel otherwise pays for it (1-2 ms in a fresh process --
+// inside hipvers' launch -> scores window).  Called when a batch that will use these kernels is created.
+void agx_sw_pack_preload()
+{
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_pack_dna));
+}
