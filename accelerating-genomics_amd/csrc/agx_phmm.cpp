@@ -194,7 +194,7 @@ struct agx_phmm_batch {
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
-    DevBuf img, sums, logs, lut, counter; // logs: float modes only (log10 taken on the device)
+    DevBuf img, sums, lut, counter;
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
     struct DevPlan {
         DevBuf groups, tabs, waves;
@@ -799,7 +799,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (!rc && !pstripe.waves.empty()) rc = b->stripe_scratch.alloc(ctx, (size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
     if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
-    if (!rc && two_pass) rc = b->logs.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double));
     if (!rc) rc = b->out_stage.alloc(ctx, 2 * (size_t)n_pairs * sizeof(double) + sizeof(unsigned long long));
     if (!rc && b->info.n_launches > 1) rc = agx_ctx_prepare_fanout(ctx);
     if (rc) return rc;
@@ -849,7 +848,6 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
         pl->waves.release();
     }
     b->sums.release();
-    b->logs.release();
     b->out_stage.release();
     b->lut.release();
     b->counter.release();
@@ -982,13 +980,14 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     double *s = nullptr, *dev_logs = nullptr;
     hipStream_t st = b->ctx->stream;
     if (f32 && b->n_pairs) {
-        if (agx_phmm_finish_launch((const double *)b->sums.p, (double *)b->logs.p, (uint32_t)b->n_pairs, c64, c32,
+        // the log10 kernel stores straight into page-locked host memory -- the caller's array when that is page-locked
+        // (agx_host_alloc), else the staging block: consecutive 8-byte stores, no D2H copy behind the kernel
+        dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at;
+        if (agx_phmm_finish_launch((const double *)b->sums.p, dev_logs, (uint32_t)b->n_pairs, c64, c32,
                                    (const unsigned long long *)b->counter.p, host_counter, st)) {
             agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }
-        dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at; // page-locked destination: no staging copy
-        AGX_HIP(hipMemcpyAsync(dev_logs, b->logs.p, sum_bytes, hipMemcpyDeviceToHost, st));
         at += sum_bytes;
     }
     if (want_sums) {
