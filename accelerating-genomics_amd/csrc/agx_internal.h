@@ -138,6 +138,10 @@ static inline int agx_bind(const agx_ctx *c)
 // the launch -> scores window of a fresh process.  Memory pinned by other means is treated as pageable (staged).
 bool agx_is_pinned_host(const void *p, size_t bytes);
 
+// device -> page-locked host memory by a kernel on stream s (agx_copy_kernel.hip); both pointers 16-byte aligned
+int agx_copy_out_launch(const void *src, void *dst, size_t bytes, hipStream_t s);
+void agx_copy_preload();
+
 // Process-wide contexts for the entry points that take device ordinals instead of a context
 // (agx_*_devices, agx_*_multi, agx_pairHMM): created on first use, kept until the process ends.
 // slot distinguishes several shards mapped onto the same device.

@@ -725,6 +725,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (ctx) {
         if (packed) agx_phmm_pk_preload();
         agx_phmm_scalar_preload();
+        agx_copy_preload();
         if (precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA) agx_phmm_finish_preload();
     }
     b->separate_rescue = packed;
@@ -799,7 +800,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (!rc && !pstripe.waves.empty()) rc = b->stripe_scratch.alloc(ctx, (size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
     if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
-    if (!rc) rc = b->out_stage.alloc(ctx, 2 * (size_t)n_pairs * sizeof(double) + sizeof(unsigned long long));
+    if (!rc) rc = b->out_stage.alloc(ctx, 2 * (size_t)n_pairs * sizeof(double) + 16);
     if (!rc && b->info.n_launches > 1) rc = agx_ctx_prepare_fanout(ctx);
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
@@ -976,7 +977,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     char *at = (char *)b->out_stage.p; // [rescue counter][logs (float modes)][sums (when wanted)]
     unsigned long long *host_counter = (unsigned long long *)at; // written by the finish kernel itself (float modes only:
     *host_counter = 0;                                           // the double modes have no rescue pass)
-    at += sizeof(double);
+    at += 16;
     double *s = nullptr, *dev_logs = nullptr;
     hipStream_t st = b->ctx->stream;
     if (f32 && b->n_pairs) {
@@ -992,7 +993,10 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     }
     if (want_sums) {
         s = (double *)at;
-        if (b->n_pairs) AGX_HIP(hipMemcpyAsync(s, b->sums.p, sum_bytes, hipMemcpyDeviceToHost, st));
+        if (b->n_pairs && agx_copy_out_launch(b->sums.p, s, sum_bytes, st)) {
+            agx_set_error("agx_phmm_batch_results: copy kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return AGX_E_HIP;
+        }
         at += sum_bytes;
     }
     AGX_HIP(hipStreamSynchronize(st));

@@ -529,6 +529,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     b->rising = rising;
     if (ctx) { // the code objects this batch will launch from, loaded now rather than inside its first launch
         agx_sw_pack_preload();
+        agx_copy_preload();
         if (family == 2) agx_sw_pk2_preload();
         if (family == 0 && !matrix) agx_sw_i32_preload();
     }
@@ -1135,22 +1136,16 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
         AGX_HIP(hipStreamSynchronize(b->ctx->stream));
         return AGX_OK;
     }
-    // one DMA right behind the last kernel on the launch stream: straight into the caller's array when that is
-    // page-locked (agx_host_alloc), else through pinned staging and a host copy (a pageable destination would
-    // make the runtime stage the copy itself, later and slower)
     const size_t bytes = (size_t)b->n_pairs * sizeof(int32_t);
-    if (agx_is_pinned_host(scores, bytes)) {
-        AGX_HIP(hipMemcpyAsync(scores, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
-        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
-        return AGX_OK;
-    }
-    hipError_t e = hipMemcpyAsync(b->out_stage.p, b->scores.p, bytes, hipMemcpyDeviceToHost, b->ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(b->ctx->stream);
-    if (e == hipSuccess) memcpy(scores, b->out_stage.p, bytes);
-    if (e != hipSuccess) {
-        agx_set_error("agx_sw_batch_scores: %s", hipGetErrorString(e));
+    // one copy kernel right behind the last fill on the launch stream: straight into the caller's array when that is
+    // page-locked (agx_host_alloc), else into pinned staging and a host copy from there
+    int32_t *dst = agx_is_pinned_host(scores, bytes) ? scores : (int32_t *)b->out_stage.p;
+    if (agx_copy_out_launch(b->scores.p, dst, bytes, b->ctx->stream)) {
+        agx_set_error("agx_sw_batch_scores: copy kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         return AGX_E_HIP;
     }
+    AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (dst != scores) memcpy(scores, dst, bytes);
     return AGX_OK;
 }
 
