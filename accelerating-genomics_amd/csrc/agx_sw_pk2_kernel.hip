@@ -1,29 +1,31 @@
 // Smith-Waterman fill, packed variant, second formulation ("biased"): the schedule and data layout of
 // agx_sw_pk_kernel.hip -- two alignment pairs per lane group, pair A in the low and pair B in the
-// high 16 bits of every state register -- with the cell rewritten for the issue rates measured on
-// gfx950 (tools/valu_microbench2.hip, profiles/r02_valu_microbench2.log):
+// high 16 bits of every state register -- with the cell rewritten around what gfx950 issues cheaply
+// (tools/valu_microbench2.hip, valu_microbench3.hip: every VALU instruction of this mix costs one 4.2-cycle
+// slot per wave64, so the instruction COUNT is what matters):
 //
-//   * v_add_u32 / v_sub_u32 / v_xor_b32 with VGPR-only operands issue in about 2.4 cycles per wave64,
-//     every v_pk_* instruction in 4.2.  All four additions of the recurrence therefore run as plain
-//     32-bit adds on both halves at once.  No carry or borrow may cross bit 16, so every value is kept
-//     as an UNSIGNED half with a bias B added: stored = true + B >= 0 always, constants are subtracted
-//     (never added as two's complement), and the vertical gap state is kept clamped at zero
-//     (P~ = max(P, 0): a negative P never reaches H -- H >= 0 -- and its successors P - 1, P - 2, ... are
-//     negative too, so max(H_up + gf, P~_up + ge, 0) = max(P_new, 0) exactly).  That clamp is also what
-//     delivers the zero floor of antidiagonalSmithWaterman.c:333: H = max(P~, Q, H_diag + s) >= 0.
+//   * Every value is kept as an UNSIGNED half with a bias B added: stored = true + B >= 0 always, constants
+//     are subtracted (never added as two's complement), so one 32-bit add serves both halves and no carry or
+//     borrow crosses bit 16.  The vertical gap state is kept clamped at zero (P~ = max(P, 0): a negative P
+//     never reaches H -- H >= 0 -- and its successors P - 1, P - 2, ... are negative too, so
+//     max(H_up + gf, P~_up + ge, 0) = max(P_new, 0) exactly).  That clamp is also what delivers the zero
+//     floor of antidiagonalSmithWaterman.c:333: H = max(P~, Q, H_diag + s) >= 0.
 //   * gfx950 has a packed three-input maximum, v_pk_maximum3_f16.  With B >= 1024 + |gf| + delta and all
 //     values below 0x7c00 every stored half is the bit pattern of a positive NORMAL half-precision number,
 //     and for those the floating-point order is the integer order: the instruction is an exact unsigned
 //     max3 here.  It folds the clamp into the gap maximum and the two maxima of :333 into one.
 //
-//   per two cells:  e' = max3(z_up, e - |ge|, B)         v_sub_u32, v_pk_maximum3_f16     (:313, clamped)
+//   general plain cell, per two cells (10.5 instructions):
+//                   e' = max3(z_up, e - |ge|, B)         v_sub_u32, v_pk_maximum3_f16     (:313, clamped)
 //                   f  = max(z_left, f - |ge|)           v_sub_u32, v_pk_max_u16          (:321)
 //                   m  = min(x ^ y, delta)               v_xor_b32, v_pk_min_u16          (:332, match test)
 //                   u  = (z_diag + hd) - m               v_add_u32, v_sub_u32             (:332)
 //                   H' = max3(e', f, u)                  v_pk_maximum3_f16                (:333)
 //                   z  = H' - |gf|                       v_sub_u32
 //                   best = max3(best, z, z_next)         half a v_pk_maximum3_f16         (:335)
-//   = 6 full-rate + 4.5 packed instructions against 1 + 11 in agx_sw_pk_kernel.hip.
+//   DNA-coded rising cell (7.5): the match term is one v_perm_b32 table lookup for both pairs, fused with the
+//   diagonal add into v_add3_u32 (FAST, below), and stored values rise by |ge| per step so that the vertical gap
+//   needs no subtraction (RISE, below).  12 in agx_sw_pk_kernel.hip.
 //
 // The host picks this kernel when the scoring and the longest shorter side keep every stored half in
 // [0x0400, 0x7c00) (agx_sw.cpp; always true for the reference's +1/-1/-3/-1 up to 2560 columns);
