@@ -191,7 +191,9 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
 
     auto fill = [&](auto hapn_tag) {
         constexpr bool HAPN = decltype(hapn_tag)::value;
-        for (int t = 0; t < steps; ++t) {
+        // (two steps per trip: the values a step hands to the next one -- pM, pX, pY -- then change registers by
+        // renaming instead of six v_mov per step)
+        auto one_step = [&](int t) __attribute__((always_inline)) {
             const float4 ra = trow[2 * t], rb = trow[2 * t + 1];
             const float pm = ra.x, pq = ra.y;
             const uint32_t rc = __float_as_uint(rb.w);
@@ -287,7 +289,13 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
                 part_a = (double)tot.x;
                 part_b = (double)tot.y;
             }
+        };
+        int t = 0;
+        for (; t + 1 < steps; t += 2) {
+            one_step(t);
+            one_step(t + 1);
         }
+        if (t < steps) one_step(t);
     };
     if (!FAST && __any((na | nb) != 0))
         fill(std::true_type{});
