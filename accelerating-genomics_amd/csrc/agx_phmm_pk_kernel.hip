@@ -291,11 +291,16 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             }
         };
         int t = 0;
-        for (; t + 1 < steps; t += 2) {
-            one_step(t);
-            one_step(t + 1);
-        }
-        if (t < steps) one_step(t);
+        // (only the builds with registers to spare: the plain cell at widths 19, 31, 32 sits at its cap and spills 40-100
+        // values when two steps are in flight)
+        if constexpr (FAST && ROW16) {
+            for (; t + 1 < steps; t += 2) {
+                one_step(t);
+                one_step(t + 1);
+            }
+            if (t < steps) one_step(t);
+        } else
+            for (; t < steps; ++t) one_step(t);
     };
     if (!FAST && __any((na | nb) != 0))
         fill(std::true_type{});
