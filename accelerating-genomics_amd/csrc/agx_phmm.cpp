@@ -192,6 +192,8 @@ struct agx_phmm_batch {
     bool gatk_prior = false;
     int64_t n_pairs = 0;
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
+    bool rescue_pending = false;  // packed batches: the rescue plan has not run for the last launch (it runs from
+                                  // agx_phmm_batch_results, and only when the fill counted a pair below the float range)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
     DevBuf img, sums, lut, counter;
@@ -799,7 +801,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         if (!rc) rc = pc.dst->alloc(ctx, pc.bytes);
     if (!rc && !pstripe.waves.empty()) rc = b->stripe_scratch.alloc(ctx, (size_t)b->stripe_grid * 6u * b->stripe_rows * sizeof(double));
     if (!rc) rc = b->sums.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(double)); // +1: spare slot of vacant packed halves
-    if (!rc) rc = b->counter.alloc(ctx, sizeof(unsigned long long));
+    if (!rc) rc = b->counter.alloc(ctx, 2 * sizeof(unsigned long long)); // [0] rescued, [1] below the float range
     if (!rc) rc = b->out_stage.alloc(ctx, 2 * (size_t)n_pairs * sizeof(double) + 16);
     if (!rc && b->info.n_launches > 1) rc = agx_ctx_prepare_fanout(ctx);
     if (rc) return rc;
@@ -881,7 +883,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
     const void *mis_f = (const char *)b->lut.p + 256 * (2 * sizeof(double) + sizeof(float));
     const bool f32_family = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
-    if (f32_family) AGX_HIP(hipMemsetAsync(b->counter.p, 0, sizeof(unsigned long long), s));
+    if (f32_family) AGX_HIP(hipMemsetAsync(b->counter.p, 0, 2 * sizeof(unsigned long long), s));
+    b->rescue_pending = b->separate_rescue;
     const void *mis_for_d = b->gatk_prior ? mis_d : nullptr, *mis_for_f = b->gatk_prior ? mis_f : nullptr;
     auto launch_scalar = [&](const agx_phmm_batch::DevPlan &pl, const ClassLaunch &cl, int mode, hipStream_t st) -> int {
         const bool f64 = mode != 2;
@@ -922,7 +925,9 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                 const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->fast, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
                                                        (const PhTab *)b->main.tabs.p,
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
-                                                       mis_for_f, (double *)b->sums.p, cl.lds, st);
+                                                       mis_for_f, (double *)b->sums.p,
+                                                       PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1},
+                                                       cl.lds, st);
                 if (r) {
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
                     return AGX_E_HIP;
@@ -939,19 +944,30 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         rc = fan.end();
         if (rc) return rc;
     }
-    if (b->separate_rescue) { // packed float fill done on every stream: now the double rescue plan
-        FanOut fan(b->ctx, (int)b->rescue.launches.size());
-        rc = fan.begin();
-        if (rc) return rc;
-        int k = 0;
-        for (const ClassLaunch &cl : b->rescue.launches) {
-            rc = launch_scalar(b->rescue, cl, 3, fan.stream(k++));
-            if (rc) return rc;
-        }
-        rc = fan.end();
-        if (rc) return rc;
-    }
     return AGX_OK;
+}
+
+// The double rescue plan of a packed float batch (its own records over the same pairs): every wave looks at its pairs'
+// float sums and recomputes those below the float range.  Run from agx_phmm_batch_results, when the fill counted any.
+static int launch_rescue_plan(agx_phmm_batch *b)
+{
+    const void *lut_d = b->lut.p;
+    const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
+    FanOut fan(b->ctx, (int)b->rescue.launches.size());
+    int rc = fan.begin();
+    if (rc) return rc;
+    int k = 0;
+    for (const ClassLaunch &cl : b->rescue.launches) {
+        const int r = agx_phmm_launch_class(3, cl.C, cl.all_g16, (const uint32_t *)b->img.p, (const PhGroup *)b->rescue.groups.p,
+                                            (const PhTab *)b->rescue.tabs.p, (const PhWave *)b->rescue.waves.p + cl.first_wave, cl.n_waves,
+                                            lut_d, b->gatk_prior ? mis_d : nullptr, (double *)b->sums.p, (double)AGX_PHMM_F32_RESCUE,
+                                            (unsigned long long *)b->counter.p, cl.lds, fan.stream(k++));
+        if (r) {
+            agx_set_error("phmm_fill<C=%d, rescue> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
+            return AGX_E_HIP;
+        }
+    }
+    return fan.end();
 }
 
 int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum)
@@ -974,33 +990,42 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     // the reference's output), by the device for the float modes (agx_phmm_finish_kernel.hip)
     const double c64 = log10(DBL_MAX / 16), c32 = log10((double)(FLT_MAX / 16));
     const bool want_sums = raw_sum != nullptr || !f32;
-    char *at = (char *)b->out_stage.p; // [rescue counter][logs (float modes)][sums (when wanted)]
-    unsigned long long *host_counter = (unsigned long long *)at; // written by the finish kernel itself (float modes only:
-    *host_counter = 0;                                           // the double modes have no rescue pass)
-    at += 16;
-    double *s = nullptr, *dev_logs = nullptr;
+    char *const stage = (char *)b->out_stage.p; // [two counters][logs (float modes)][sums (when wanted)]
+    volatile unsigned long long *host_counter = (volatile unsigned long long *)stage; // written by the log10 kernel itself
+    double *s = nullptr, *dev_logs = nullptr;                                         // (float modes; the double modes have no rescue pass)
     hipStream_t st = b->ctx->stream;
-    if (f32 && b->n_pairs) {
-        // the log10 kernel stores straight into page-locked host memory -- the caller's array when that is page-locked
-        // (agx_host_alloc), else the staging block: consecutive 8-byte stores, no D2H copy behind the kernel
-        dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at;
-        if (agx_phmm_finish_launch((const double *)b->sums.p, dev_logs, (uint32_t)b->n_pairs, c64, c32,
-                                   (const unsigned long long *)b->counter.p, host_counter, st)) {
-            agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
-            return AGX_E_HIP;
+    for (int round = 0; round < 2; ++round) {
+        host_counter[0] = host_counter[1] = 0;
+        char *at = stage + 16;
+        if (f32 && b->n_pairs) {
+            // the log10 kernel stores straight into page-locked host memory -- the caller's array when that is
+            // page-locked (agx_host_alloc), else the staging block: consecutive 8-byte stores, no D2H copy behind it
+            dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at;
+            if (agx_phmm_finish_launch((const double *)b->sums.p, dev_logs, (uint32_t)b->n_pairs, c64, c32,
+                                       (const unsigned long long *)b->counter.p, (unsigned long long *)stage, st)) {
+                agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return AGX_E_HIP;
+            }
+            at += sum_bytes;
         }
-        at += sum_bytes;
-    }
-    if (want_sums) {
-        s = (double *)at;
-        if (b->n_pairs && agx_copy_out_launch(b->sums.p, s, sum_bytes, st)) {
-            agx_set_error("agx_phmm_batch_results: copy kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-            return AGX_E_HIP;
+        if (want_sums) {
+            s = (double *)at;
+            if (b->n_pairs && agx_copy_out_launch(b->sums.p, s, sum_bytes, st)) {
+                agx_set_error("agx_phmm_batch_results: copy kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return AGX_E_HIP;
+            }
+            at += sum_bytes;
         }
-        at += sum_bytes;
+        AGX_HIP(hipStreamSynchronize(st));
+        // a packed float batch launches its double rescue plan only now, and only when the fill counted a pair below
+        // the float range (config 3: never) -- then the results are taken a second time
+        if (!(b->rescue_pending && host_counter[1] != 0)) break;
+        b->rescue_pending = false;
+        rc = launch_rescue_plan(b);
+        if (rc) return rc;
     }
-    AGX_HIP(hipStreamSynchronize(st));
-    b->info.n_rescued = (int64_t)*(volatile unsigned long long *)host_counter;
+    b->rescue_pending = false;
+    b->info.n_rescued = (int64_t)host_counter[0];
     if (f32) {
         if (b->n_pairs && dev_logs != log10_lik) memcpy(log10_lik, dev_logs, sum_bytes);
     } else

@@ -86,9 +86,16 @@ __host__ __device__ static inline size_t ph_pk_tab_bytes(uint32_t rows) { return
 // mode: 0 = f64 reference order, 1 = f64 with FMA contraction, 2 = f32, 3 = f64 rescue pass
 // over an f32 result (only groups whose sums[out] < rescue_below are recomputed), 4 = f64
 // reference order with probability tracks instead of Phred characters (pairHMM() seam).
+// The packed float fill counts the pairs whose sum came out below the float range (`below`; indices >= n_pairs are the
+// spare slot of vacant halves): the double rescue plan is launched only when that count is not zero.
+struct PhUnderflow {
+    double below;
+    uint32_t n_pairs;
+    unsigned long long *count;
+};
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
-                             size_t lds_bytes, hipStream_t s);
+                             const PhUnderflow &uf, size_t lds_bytes, hipStream_t s);
 // Haplotypes no class can span (more than 64 lanes x the widest class of the batch's arithmetic) run
 // one pair per wavefront in stripes of 64 x AGX_PH_STRIPE_COLS = 1536 columns, always in double (mode 0, 1
 // or 4).  grid workgroups walk the n_waves pairs; scratch holds 6 * scratch_rows doubles per workgroup.

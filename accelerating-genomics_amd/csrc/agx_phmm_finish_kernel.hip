@@ -17,7 +17,10 @@ __global__ void __launch_bounds__(256) phmm_finish_f32(const double *__restrict_
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     // the rescue counter goes to page-locked host memory from here: a D2H copy of its own for eight bytes cost
     // about as much as the copy of the results
-    if (k == 0) *n_rescued_host = *n_rescued;
+    if (k == 0) {
+        n_rescued_host[0] = n_rescued[0]; // pairs the rescue pass recomputed
+        n_rescued_host[1] = n_rescued[1]; // pairs the packed fill found below the float range
+    }
     if (k >= n) return;
     double v = sums[k];
     double c = log_c32;

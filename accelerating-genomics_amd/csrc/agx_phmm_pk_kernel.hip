@@ -61,7 +61,7 @@ template <int C, bool ROW16, bool FAST>
 __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                   const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                   uint32_t n_waves, const float *__restrict__ lut,
-                                                  const float *__restrict__ lut_mis, double *__restrict__ sums)
+                                                  const float *__restrict__ lut_mis, double *__restrict__ sums, const PhUnderflow uf)
 {
     constexpr int HW = (C + 3) / 4; // dwords holding this lane's C haplotype bases
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -317,6 +317,10 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     if (active && gl == G - 1) {
         sums[g.out[0]] = part_a;
         sums[g.out[1]] = part_b; // a group without a second haplotype points this at the spare slot
+        // the census the host reads with the results: any pair below the float range means the double rescue plan
+        // has to run (it is launched only then -- agx_phmm_batch_results)
+        const unsigned under = (unsigned)(!(part_a >= uf.below) && g.out[0] < uf.n_pairs) + (unsigned)(!(part_b >= uf.below) && g.out[1] < uf.n_pairs);
+        if (under) atomicAdd(uf.count, (unsigned long long)under);
     }
 }
 
@@ -324,9 +328,9 @@ template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) phmm_fill_pk(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups,
                                                    const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                    uint32_t n_waves, const float *__restrict__ lut,
-                                                   const float *__restrict__ lut_mis, double *__restrict__ sums)
+                                                   const float *__restrict__ lut_mis, double *__restrict__ sums, const PhUnderflow uf)
 {
-    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf);
 }
 
 // Same fill asked to fit three waves per SIMD (168 VGPRs).  Width 19 -- the tiling of H = 300 -- needs
@@ -335,9 +339,9 @@ template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 phmm_fill_pk_w3(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
                 const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
-                const float *__restrict__ lut_mis, double *__restrict__ sums)
+                const float *__restrict__ lut_mis, double *__restrict__ sums, const PhUnderflow uf)
 {
-    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf);
 }
 
 // ... and two waves per SIMD (256 VGPRs) for widths 31 and 32 (H = 500 in 16 x 32), 257 left alone.
@@ -345,16 +349,16 @@ template <int C, bool ROW16, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_pk_w2(const uint32_t *__restrict__ img, const PhGroup2 *__restrict__ groups, const PhTab *__restrict__ tabs,
                 const PhWave *__restrict__ waves, uint32_t n_waves, const float *__restrict__ lut,
-                const float *__restrict__ lut_mis, double *__restrict__ sums)
+                const float *__restrict__ lut_mis, double *__restrict__ sums, const PhUnderflow uf)
 {
-    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_fill_pk_body<C, ROW16, FAST>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf);
 }
 
 template <int C, bool ROW16, bool FAST>
 int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
-           const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
+           const void *lut, const void *lut_mis, double *sums, const PhUnderflow &uf, size_t lds, hipStream_t s)
 {
-    void (*k)(const uint32_t *, const PhGroup2 *, const PhTab *, const PhWave *, uint32_t, const float *, const float *, double *);
+    void (*k)(const uint32_t *, const PhGroup2 *, const PhTab *, const PhWave *, uint32_t, const float *, const float *, double *, PhUnderflow);
     if constexpr (C == kPkThreeWaveWidth)
         k = phmm_fill_pk_w3<C, ROW16, FAST>;
     else if constexpr (C > 30)
@@ -366,7 +370,7 @@ int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const
             return -1;
     }
     hipLaunchKernelGGL(k, dim3(n_waves), dim3(64), lds, s, img, groups, tabs, waves, n_waves, (const float *)lut,
-                       (const float *)lut_mis, sums);
+                       (const float *)lut_mis, sums, uf);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -374,16 +378,16 @@ int launch(const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs, const
 
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
-                             size_t lds_bytes, hipStream_t s)
+                             const PhUnderflow &uf, size_t lds_bytes, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_PH_PK_CASE(CC) \
     case CC: \
-        return all_groups_16 ? (fast ? launch<CC, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
-                                       : launch<CC, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s)) \
-                             : (fast ? launch<CC, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s) \
-                                       : launch<CC, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s));
+        return all_groups_16 ? (fast ? launch<CC, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf, lds_bytes, s) \
+                                       : launch<CC, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf, lds_bytes, s)) \
+                             : (fast ? launch<CC, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf, lds_bytes, s) \
+                                       : launch<CC, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, uf, lds_bytes, s));
         AGX_PH_FOR_EACH_PK_CLASS(AGX_PH_PK_CASE)
 #undef AGX_PH_PK_CASE
     default: return -2;
