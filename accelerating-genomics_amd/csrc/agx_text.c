@@ -163,6 +163,13 @@ int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out)
 
 int32_t agx_sw_reader_line_num(const agx_sw_reader *r) { return r ? r->line_num : -1; }
 
+/*
+ * One chunk of pairs.  The lines of a chunk are consecutive bytes of the file, newline included (:229-247 keep it), so the
+ * chunk's `bases` array IS a piece of the file: it is read straight into that array and only scanned -- one memchr per
+ * line for the newline, one per block for a NUL byte (the strlen() rule; per line only when the block has one) -- where
+ * the first version copied every line out of a block buffer (fread, two memchr, memcpy: 2.3 GB/s; now about twice that).
+ * Bytes read beyond the chunk's last line go back into the reader's buffer for the next chunk.
+ */
 int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
 {
     if (!r || !out) {
@@ -175,46 +182,120 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
     int rc = AGX_E_NOMEM;
     if (!t) goto done;
     t->line_num = r->line_num;
-    if (r->hint_pairs) { /* a chunk like the last one: no regrowing (and recopying) of 100+ MB buffers */
-        const size_t np = r->hint_pairs < (size_t)max_pairs ? r->hint_pairs : (size_t)max_pairs;
-        if (buf_reserve(&bases, r->hint_bases + r->hint_bases / 16 + 4096) || buf_reserve(&off, 2 * np * sizeof(uint64_t)) ||
-            buf_reserve(&len, 2 * np * sizeof(uint32_t)))
-            goto done;
+    {
+        /* how many bytes this chunk will probably take: the previous chunk's bytes per pair, else the file's size */
+        const int64_t lines_left = (int64_t)r->line_num - r->lines_taken;
+        int64_t want = lines_left > 0 ? (lines_left + 1) / 2 : 0;
+        if (want > max_pairs) want = max_pairs;
+        size_t est = (size_t)64 << 20;
+        if (r->hint_pairs)
+            est = (size_t)((double)r->hint_bases / (double)r->hint_pairs * (double)want * 1.03) + 65536;
+        else {
+            const long at = ftell(r->f);
+            if (at >= 0 && fseek(r->f, 0, SEEK_END) == 0) {
+                const long end = ftell(r->f);
+                if (end >= at && (size_t)(end - at) < est) est = (size_t)(end - at);
+                (void)fseek(r->f, at, SEEK_SET);
+            }
+        }
+        const size_t carry = r->hi - r->lo;
+        if (buf_reserve(&bases, carry + est + 4096)) goto done;
+        if (carry) memcpy(bases.p, r->buf + r->lo, carry);
+        bases.n = carry; /* bytes present in the chunk's array */
+        r->lo = r->hi = 0;
+        if (want > 0 && (buf_reserve(&off, 2 * (size_t)want * sizeof(uint64_t)) || buf_reserve(&len, 2 * (size_t)want * sizeof(uint32_t)))) goto done;
     }
-    while (!r->finished && t->n_pairs < max_pairs) {
-        if (r->lines_taken >= r->line_num) { /* loop condition of :216 */
-            r->finished = 1;
-            break;
+    {
+        const size_t max = (size_t)r->line_buf - 1;
+        size_t lo = 0;        /* first byte not yet given to a pair */
+        size_t nul_seen = 0;  /* [0, nul_seen) has been searched for NUL bytes */
+        int has_nul = 0;
+        /* one line at `at`: its fgets length in *flen, its strlen in *slen; 1 = found, 0 = no line left, -1 = needs more bytes */
+#define AGX_LINE_AT(at, flen, slen)                                                                                   \
+    do {                                                                                                              \
+        const size_t have_ = bases.n - (at);                                                                          \
+        const size_t look_ = have_ < max ? have_ : max;                                                               \
+        const unsigned char *q_ = bases.p + (at);                                                                     \
+        const unsigned char *nl_ = look_ ? (const unsigned char *)memchr(q_, '\n', look_) : NULL;                     \
+        if (nl_) (flen) = (size_t)(nl_ - q_) + 1, got_ = 1;                                                           \
+        else if (look_ == max) (flen) = max, got_ = 1;      /* an over-long line splits where fgets would */          \
+        else if (r->eof) (flen) = have_, got_ = have_ ? 1 : 0; /* last line without a newline */                      \
+        else got_ = -1;                                                                                               \
+        if (got_ == 1) {                                                                                              \
+            (slen) = (flen);                                                                                          \
+            if (has_nul) {                                                                                            \
+                const unsigned char *z_ = (const unsigned char *)memchr(q_, 0, (flen));                               \
+                if (z_) (slen) = (size_t)(z_ - q_);                                                                   \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
+        while (!r->finished && t->n_pairs < max_pairs) {
+            if (r->lines_taken >= r->line_num) { /* loop condition of :216 */
+                r->finished = 1;
+                break;
+            }
+            if (nul_seen < bases.n) {
+                if (!has_nul && memchr(bases.p + nul_seen, 0, bases.n - nul_seen)) has_nul = 1;
+                nul_seen = bases.n;
+            }
+            int got_;
+            size_t f1 = 0, s1 = 0, f2 = 0, s2 = 0;
+            AGX_LINE_AT(lo, f1, s1);
+            int need_more = got_ < 0;
+            if (got_ == 0) { /* :219-221 */
+                r->finished = 1;
+                break;
+            }
+            if (!need_more) {
+                AGX_LINE_AT(lo + f1, f2, s2);
+                need_more = got_ < 0;
+                if (got_ == 0) { /* :223-227: the first line is echoed, loop ends */
+                    t->dangling = (char *)malloc(s1 + 1);
+                    if (!t->dangling) goto done;
+                    memcpy(t->dangling, bases.p + lo, s1);
+                    t->dangling[s1] = 0;
+                    r->finished = 1;
+                    break;
+                }
+            }
+            if (need_more) { /* the pair at `lo` is not complete: more of the file, then look at it again */
+                if (bases.n + ((size_t)1 << 20) > bases.cap && buf_reserve(&bases, bases.cap / 2 + ((size_t)16 << 20))) goto done;
+                /* in slices that stay in the cache while they are scanned (one read() of the whole chunk streamed it
+                   through memory three times: 1.3 instead of 0.45 s for 573 MB) */
+                size_t slice = bases.cap - bases.n;
+                if (slice > ((size_t)4 << 20)) slice = (size_t)4 << 20;
+                const size_t got = fread(bases.p + bases.n, 1, slice, r->f);
+                bases.n += got;
+                if (got == 0) r->eof = 1;
+                continue;
+            }
+            const uint64_t o1 = lo, o2 = lo + f1;
+            const uint32_t l1 = (uint32_t)s1, l2 = (uint32_t)s2; /* newline included, :229-247 */
+            if (buf_put(&off, &o1, sizeof o1) || buf_put(&len, &l1, sizeof l1) || buf_put(&off, &o2, sizeof o2) || buf_put(&len, &l2, sizeof l2))
+                goto done;
+            lo += f1 + f2;
+            t->n_pairs++;
+            r->lines_taken += 2;
         }
-        const char *p;
-        size_t n1, n2;
-        if (!reader_line(r, &p, &n1)) { /* :219-221 */
-            r->finished = 1;
-            break;
+#undef AGX_LINE_AT
+        /* what was read beyond this chunk belongs to the next one */
+        const size_t left = r->finished ? 0 : bases.n - lo;
+        if (left) {
+            if (left > r->cap) {
+                char *nb = (char *)realloc(r->buf, left);
+                if (!nb) goto done;
+                r->buf = nb;
+                r->cap = left;
+            }
+            memcpy(r->buf, bases.p + lo, left);
         }
-        const uint64_t o1 = bases.n;
-        if (buf_put(&bases, p, n1)) goto done;
-        if (!reader_line(r, &p, &n2)) { /* :223-227: the first line is echoed, loop ends */
-            t->dangling = (char *)malloc(n1 + 1);
-            if (!t->dangling) goto done;
-            memcpy(t->dangling, bases.p + o1, n1);
-            t->dangling[n1] = 0;
-            bases.n = (size_t)o1;
-            r->finished = 1;
-            break;
-        }
-        const uint64_t o2 = bases.n;
-        const uint32_t l1 = (uint32_t)n1, l2 = (uint32_t)n2; /* newline included, :229-247 */
-        if (buf_put(&bases, p, n2) || buf_put(&off, &o1, sizeof o1) || buf_put(&len, &l1, sizeof l1) ||
-            buf_put(&off, &o2, sizeof o2) || buf_put(&len, &l2, sizeof l2))
-            goto done;
-        t->n_pairs++;
-        r->lines_taken += 2;
+        r->lo = 0;
+        r->hi = left;
+        r->hint_bases = lo;
     }
     t->bases = bases.p;
     t->off = (uint64_t *)off.p;
     t->len = (uint32_t *)len.p;
-    r->hint_bases = bases.n;
     r->hint_pairs = (size_t)t->n_pairs;
     bases.p = off.p = len.p = NULL;
     rc = AGX_OK;
