@@ -95,6 +95,13 @@ Pool &pool()
 
 int agx_host_threads() { return pool().parts; }
 
+// the pool for the C readers (agx_text.c)
+extern "C" int agx_host_threads_c(void) { return agx_host_threads(); }
+extern "C" void agx_pool_run_c(int parts, void (*task)(int, void *), void *arg)
+{
+    agx_pool_run(parts, [&](int t) { task(t, arg); });
+}
+
 void agx_pool_run(int parts, const std::function<void(int)> &task)
 {
     if (parts <= 1) {

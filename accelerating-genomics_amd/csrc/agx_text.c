@@ -9,11 +9,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "agx.h"
 
 /* implemented in agx_runtime.cpp */
 extern void agx_set_error(const char *fmt, ...);
+extern int agx_host_threads_c(void);                                               /* the process-wide host thread pool */
+extern void agx_pool_run_c(int parts, void (*task)(int part, void *arg), void *arg);
 
 /* ------------------------------------------------------------ growable byte/array helpers */
 
@@ -70,6 +74,8 @@ struct agx_sw_reader {
     size_t cap, lo, hi;
     int eof;
     size_t hint_bases, hint_pairs; /* size of the previous chunk: the next one reserves that much up front */
+    int regular;                   /* a regular file: chunks are read with pread() by several threads */
+    off_t pos, size;               /* next file byte not yet read into a chunk or the buffer; the file's size */
 };
 
 /* next line -> *p (valid until the next call), its strlen() in *n; 0 = no line left */
@@ -157,11 +163,137 @@ int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out)
     memcpy(head, p, hn);
     head[hn] = 0;
     r->line_num = atoi(head); /* number of sequence LINES, :209 */
+    {
+        struct stat st;
+        const long at = ftell(r->f);
+        if (at >= 0 && fstat(fileno(r->f), &st) == 0 && S_ISREG(st.st_mode)) {
+            r->regular = 1;
+            r->pos = (off_t)at; /* the block buffer holds the bytes before it */
+            r->size = st.st_size;
+        }
+    }
     *out = r;
     return AGX_OK;
 }
 
 int32_t agx_sw_reader_line_num(const agx_sw_reader *r) { return r ? r->line_num : -1; }
+
+/* ------------------------------------------------------------------ parallel chunk scan (regular files)
+ * A chunk's bytes are read by T threads (pread of one slice each) and scanned by T threads: a thread owns the physical
+ * lines -- newline to newline -- that START in its slice, follows the last of them into the next slices, and cuts every
+ * physical line into fgets() lines from its start (at most line_buf - 1 bytes each).  After a newline the reader's state
+ * is independent of what came before, which is what makes the slices independent.
+ */
+typedef struct {
+    uint64_t off;
+    uint32_t flen, slen; /* bytes fgets() consumes / strlen() of what it returns */
+} sw_line;
+
+typedef struct {
+    unsigned char *base; /* the chunk's bases array */
+    size_t carry, n;     /* bytes present before the read; bytes present after it */
+    size_t slice;        /* bytes per part (scan: of [0, n); read: of [carry, n)) */
+    int parts, fd, eof, has_nul, oom, io_error;
+    off_t pos;
+    size_t max;          /* line_buf - 1 */
+    sw_line **lines;
+    size_t *n_lines;
+    size_t tail;         /* first byte of an incomplete last line, or n */
+    uint64_t *off;       /* fill pass: destination arrays, lines to write, first global line of every part */
+    uint32_t *len;
+    size_t used_lines, *first_line;
+} sw_scan;
+
+static void sw_read_part(int part, void *arg)
+{
+    sw_scan *j = (sw_scan *)arg;
+    const size_t a = j->carry + (size_t)part * j->slice;
+    size_t b = a + j->slice;
+    if (b > j->n || part == j->parts - 1) b = j->n;
+    size_t at = a;
+    while (at < b) { /* pread may return short counts */
+        const ssize_t got = pread(j->fd, j->base + at, b - at, j->pos + (off_t)(at - j->carry));
+        if (got <= 0) {
+            j->io_error = 1;
+            return;
+        }
+        at += (size_t)got;
+    }
+    if (b > a && memchr(j->base + a, 0, b - a)) j->has_nul = 1;
+}
+
+static void sw_scan_part(int part, void *arg)
+{
+    sw_scan *j = (sw_scan *)arg;
+    const unsigned char *base = j->base;
+    const size_t n = j->n, max = j->max;
+    const size_t a = (size_t)part * j->slice;
+    size_t b = a + j->slice;
+    if (b > n || part == j->parts - 1) b = n;
+    size_t pos = a;
+    if (part > 0 && base[a - 1] != '\n') { /* the slice begins inside a physical line owned by an earlier part */
+        const unsigned char *q = a < b ? (const unsigned char *)memchr(base + a, '\n', b - a) : NULL;
+        if (!q) return;
+        pos = (size_t)(q - base) + 1;
+    }
+    size_t cap = (b - a) / 96 + 64, cnt = 0;
+    sw_line *out = (sw_line *)malloc(cap * sizeof *out);
+    if (!out) {
+        j->oom = 1;
+        return;
+    }
+    while (pos < b) { /* one physical line per trip */
+        for (;;) {
+            const size_t have = n - pos, look = have < max ? have : max;
+            const unsigned char *q = base + pos;
+            const unsigned char *nl = look ? (const unsigned char *)memchr(q, '\n', look) : NULL;
+            size_t flen;
+            int ends;
+            if (nl) flen = (size_t)(nl - q) + 1, ends = 1;
+            else if (look == max) flen = max, ends = 0; /* an over-long line splits where fgets would */
+            else if (j->eof && have) flen = have, ends = 1; /* last line without a newline */
+            else {
+                j->tail = pos; /* incomplete (or nothing left): only the part that reaches n gets here */
+                goto done;
+            }
+            size_t slen = flen;
+            if (j->has_nul) {
+                const unsigned char *z = (const unsigned char *)memchr(q, 0, flen);
+                if (z) slen = (size_t)(z - q);
+            }
+            if (cnt == cap) {
+                sw_line *g = (sw_line *)realloc(out, 2 * cap * sizeof *out);
+                if (!g) {
+                    free(out);
+                    j->oom = 1;
+                    return;
+                }
+                out = g;
+                cap *= 2;
+            }
+            out[cnt].off = pos;
+            out[cnt].flen = (uint32_t)flen;
+            out[cnt].slen = (uint32_t)slen;
+            ++cnt;
+            pos += flen;
+            if (ends) break;
+        }
+    }
+done:
+    j->lines[part] = out;
+    j->n_lines[part] = cnt;
+}
+
+static void sw_fill_part(int part, void *arg)
+{
+    sw_scan *j = (sw_scan *)arg;
+    const sw_line *l = j->lines[part];
+    size_t g = j->first_line[part];
+    for (size_t k = 0; k < j->n_lines[part] && g < j->used_lines; ++k, ++g) {
+        j->off[g] = l[k].off;
+        j->len[g] = l[k].slen;
+    }
+}
 
 /*
  * One chunk of pairs.  The lines of a chunk are consecutive bytes of the file, newline included (:229-247 keep it), so the
@@ -190,20 +322,114 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
         size_t est = (size_t)64 << 20;
         if (r->hint_pairs)
             est = (size_t)((double)r->hint_bases / (double)r->hint_pairs * (double)want * 1.03) + 65536;
-        else {
-            const long at = ftell(r->f);
-            if (at >= 0 && fseek(r->f, 0, SEEK_END) == 0) {
-                const long end = ftell(r->f);
-                if (end >= at && (size_t)(end - at) < est) est = (size_t)(end - at);
-                (void)fseek(r->f, at, SEEK_SET);
-            }
-        }
+        else if (r->regular && (size_t)(r->size - r->pos) < est)
+            est = (size_t)(r->size - r->pos);
         const size_t carry = r->hi - r->lo;
         if (buf_reserve(&bases, carry + est + 4096)) goto done;
         if (carry) memcpy(bases.p, r->buf + r->lo, carry);
         bases.n = carry; /* bytes present in the chunk's array */
         r->lo = r->hi = 0;
         if (want > 0 && (buf_reserve(&off, 2 * (size_t)want * sizeof(uint64_t)) || buf_reserve(&len, 2 * (size_t)want * sizeof(uint32_t)))) goto done;
+
+        /* ---- large chunks of a regular file: read and scanned by the host thread pool */
+        size_t to_read = r->regular && r->size > r->pos ? (size_t)(r->size - r->pos) : 0;
+        if (to_read > est) to_read = est;
+        int parts = agx_host_threads_c();
+        if ((size_t)parts > to_read / ((size_t)4 << 20)) parts = (int)(to_read / ((size_t)4 << 20));
+        if (want > 0 && parts > 1) {
+            sw_scan j;
+            memset(&j, 0, sizeof j);
+            j.base = bases.p;
+            j.carry = carry;
+            j.n = carry + to_read;
+            j.parts = parts;
+            j.fd = fileno(r->f);
+            j.pos = r->pos;
+            j.max = (size_t)r->line_buf - 1;
+            j.slice = (to_read + (size_t)parts - 1) / (size_t)parts;
+            j.has_nul = carry && memchr(bases.p, 0, carry) != NULL;
+            sw_line **lines = (sw_line **)calloc((size_t)parts, sizeof *lines);
+            size_t *counts = (size_t *)calloc(2 * (size_t)parts, sizeof *counts);
+            if (!lines || !counts) {
+                free(lines);
+                free(counts);
+                goto done;
+            }
+            j.lines = lines;
+            j.n_lines = counts;
+            j.first_line = counts + parts;
+            agx_pool_run_c(parts, sw_read_part, &j);
+            int failed = j.io_error;
+            if (!failed) {
+                r->pos += (off_t)to_read;
+                bases.n = j.n;
+                j.eof = r->eof = r->pos >= r->size;
+                j.tail = j.n;
+                j.slice = (j.n + (size_t)parts - 1) / (size_t)parts;
+                agx_pool_run_c(parts, sw_scan_part, &j);
+                failed = j.oom;
+            }
+            size_t avail = 0;
+            for (int k = 0; k < parts; ++k) {
+                j.first_line[k] = avail;
+                avail += j.n_lines[k];
+            }
+            /* the pairs the reference's loop (:216-227) takes from these lines */
+            size_t pairs = avail / 2;
+            if ((int64_t)pairs > want) pairs = (size_t)want;
+            if (!failed && (buf_reserve(&off, 2 * pairs * sizeof(uint64_t) + 8) || buf_reserve(&len, 2 * pairs * sizeof(uint32_t) + 4))) failed = 1;
+            size_t used_end = j.tail; /* first byte that belongs to the next chunk */
+            if (!failed) {
+                j.off = (uint64_t *)off.p;
+                j.len = (uint32_t *)len.p;
+                j.used_lines = 2 * pairs;
+                agx_pool_run_c(parts, sw_fill_part, &j);
+                off.n = 2 * pairs * sizeof(uint64_t);
+                len.n = 2 * pairs * sizeof(uint32_t);
+                /* the line after the last one used, if this chunk holds it */
+                const sw_line *next = NULL;
+                for (int k = 0; k < parts && !next; ++k)
+                    if (j.used_lines >= j.first_line[k] && j.used_lines < j.first_line[k] + j.n_lines[k]) next = &j.lines[k][j.used_lines - j.first_line[k]];
+                if (next) used_end = (size_t)next->off;
+                t->n_pairs = (int64_t)pairs;
+                r->lines_taken += 2 * (int64_t)pairs;
+                if (r->lines_taken >= r->line_num) r->finished = 1; /* loop condition of :216 */
+                else if ((int64_t)pairs < want && r->eof) {          /* the file ends before the count does */
+                    if (next) {                                      /* :223-227: a first line without a second is echoed */
+                        t->dangling = (char *)malloc((size_t)next->slen + 1);
+                        if (!t->dangling) failed = 1;
+                        else {
+                            memcpy(t->dangling, bases.p + next->off, next->slen);
+                            t->dangling[next->slen] = 0;
+                        }
+                    }
+                    r->finished = 1;
+                }
+            }
+            for (int k = 0; k < parts; ++k) free(lines[k]);
+            free(lines);
+            free(counts);
+            if (j.io_error) {
+                agx_set_error("agx_sw_reader_next: read error: %s", strerror(errno));
+                rc = AGX_E_IO;
+                goto done_keep_error;
+            }
+            if (failed) goto done;
+            const size_t left = r->finished ? 0 : bases.n - used_end;
+            if (left) {
+                if (left > r->cap) {
+                    char *nb = (char *)realloc(r->buf, left);
+                    if (!nb) goto done;
+                    r->buf = nb;
+                    r->cap = left;
+                }
+                memcpy(r->buf, bases.p + used_end, left);
+            }
+            r->lo = 0;
+            r->hi = left;
+            r->hint_bases = used_end;
+            goto publish;
+        }
     }
     {
         const size_t max = (size_t)r->line_buf - 1;
@@ -264,7 +490,13 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
                    through memory three times: 1.3 instead of 0.45 s for 573 MB) */
                 size_t slice = bases.cap - bases.n;
                 if (slice > ((size_t)4 << 20)) slice = (size_t)4 << 20;
-                const size_t got = fread(bases.p + bases.n, 1, slice, r->f);
+                size_t got;
+                if (r->regular) {
+                    const ssize_t g = pread(fileno(r->f), bases.p + bases.n, slice, r->pos);
+                    got = g > 0 ? (size_t)g : 0;
+                    r->pos += (off_t)got;
+                } else
+                    got = fread(bases.p + bases.n, 1, slice, r->f);
                 bases.n += got;
                 if (got == 0) r->eof = 1;
                 continue;
@@ -293,6 +525,7 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
         r->hi = left;
         r->hint_bases = lo;
     }
+publish:
     t->bases = bases.p;
     t->off = (uint64_t *)off.p;
     t->len = (uint32_t *)len.p;
@@ -309,6 +542,12 @@ done:
         t = NULL;
     }
     *out = t;
+    return rc;
+done_keep_error:
+    free(bases.p);
+    free(off.p);
+    free(len.p);
+    agx_sw_text_free(t);
     return rc;
 }
 

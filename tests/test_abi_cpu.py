@@ -150,6 +150,52 @@ def test_block_reader_has_fgets_semantics_and_chunks_concatenate(tmp_path, seed,
             assert got == want and [d for d in dangs if d is not None] == ([dangling] if dangling is not None else [])
 
 
+@pytest.mark.parametrize("final_newline,odd", [(True, False), (False, True)])
+def test_parallel_chunk_reader_against_the_fgets_model(tmp_path, final_newline, odd):
+    """Chunks of 8 MB and more of a regular file are read and scanned by the host thread pool, every thread owning the
+    physical lines that start in its slice (agx_text.c).  A 30 MB file with over-long lines, NUL bytes, an optional
+    missing final newline and an odd line count, read at once and in chunks, against the byte-level model."""
+    rng = np.random.default_rng(99)
+    lens = rng.integers(0, 700, size=90000)
+    lens[rng.integers(0, lens.size, size=300)] = rng.integers(990, 4200, size=300)  # lines fgets splits
+    if odd:
+        lens = lens[:-1]
+    data = rng.integers(65, 91, size=int(lens.sum()) + lens.size, dtype=np.uint8)
+    ends = np.cumsum(lens + 1) - 1
+    data[ends] = 10
+    nul = rng.integers(0, data.size, size=200)
+    data[nul[data[nul] != 10]] = 0
+    body = data.tobytes() if final_newline else data.tobytes()[:-1]
+    assert len(body) > 24 << 20
+    lines = list(_fgets_lines(body, 1000))
+    p = tmp_path / "big.in"
+    for count in (10 ** 9, len(lines) - 5):
+        p.write_bytes(b"%d\n" % count + body)
+        want = lines[: count + (count & 1)]
+        dangling = want[-1] if len(want) % 2 else None
+        want = want[: len(want) // 2 * 2]
+        line_num, b, dang = agx.read_sw_text(str(p))
+        assert line_num == count and b.n_pairs == len(want) // 2 and dang == dangling
+        off, ln = b.off.astype(np.int64), b.len.astype(np.int64)
+        raw = b.bases.tobytes()
+        assert all(raw[off[k] : off[k] + ln[k]] == want[k] for k in range(0, 2 * b.n_pairs, 37))
+        assert [raw[off[k] : off[k] + ln[k]] for k in range(2 * b.n_pairs - 50, 2 * b.n_pairs)] == want[-50:]
+        want_len = np.array([len(x) for x in want], dtype=np.int64)
+        assert np.array_equal(ln, want_len)
+        for chunk in (20000, 10 ** 6):
+            n_got, dangs, k0 = 0, [], 0
+            for lnum, cb, d in agx.read_sw_text_chunks(str(p), chunk):
+                assert lnum == count and cb.n_pairs <= chunk
+                cl = cb.len.astype(np.int64)
+                assert np.array_equal(cl, want_len[k0 : k0 + cl.size])
+                craw, coff = cb.bases.tobytes(), cb.off.astype(np.int64)
+                for k in list(range(0, cl.size, 101)) + list(range(max(0, cl.size - 4), cl.size)):
+                    assert craw[coff[k] : coff[k] + cl[k]] == want[k0 + k]
+                k0 += cl.size
+                dangs.append(d)
+            assert k0 == len(want) and [d for d in dangs if d is not None] == ([dangling] if dangling is not None else [])
+
+
 @pytest.mark.parametrize("name", ["phmm_10s", "phmm_synth", "phmm_long"])
 @pytest.mark.parametrize("max_pairs", [1, 100, 10 ** 9])
 def test_phmm_reader_hands_out_whole_regions(golden_dir, name, max_pairs):
