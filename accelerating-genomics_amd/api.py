@@ -33,7 +33,7 @@ SYMBOLS = [
     "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
     "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_phmm_forward_devices", "agx_phmm_shard_cuts",
     "agx_pairHMM",
-    "agx_sw_text_read", "agx_sw_text_free", "agx_sw_reader_open", "agx_sw_reader_line_num", "agx_sw_reader_next",
+    "agx_sw_text_read", "agx_sw_text_free", "agx_sw_reader_open", "agx_sw_reader_line_num", "agx_sw_reader_set_threads", "agx_sw_reader_next",
     "agx_sw_reader_done", "agx_sw_reader_close", "agx_phmm_text_read", "agx_phmm_text_free",
     "agx_phmm_reader_open", "agx_phmm_reader_next", "agx_phmm_reader_done", "agx_phmm_reader_close",
 ]

@@ -75,6 +75,7 @@ struct agx_sw_reader {
     int eof;
     size_t hint_bases, hint_pairs; /* size of the previous chunk: the next one reserves that much up front */
     int regular;                   /* a regular file: chunks are read with pread() by several threads */
+    int threads;                   /* ... at most this many (0 = the pool's size) */
     off_t pos, size;               /* next file byte not yet read into a chunk or the buffer; the file's size */
 };
 
@@ -177,6 +178,11 @@ int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out)
 }
 
 int32_t agx_sw_reader_line_num(const agx_sw_reader *r) { return r ? r->line_num : -1; }
+
+void agx_sw_reader_set_threads(agx_sw_reader *r, int n_threads)
+{
+    if (r) r->threads = n_threads > 0 ? n_threads : 0;
+}
 
 /* ------------------------------------------------------------------ parallel chunk scan (regular files)
  * A chunk's bytes are read by T threads (pread of one slice each) and scanned by T threads: a thread owns the physical
@@ -335,6 +341,7 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
         size_t to_read = r->regular && r->size > r->pos ? (size_t)(r->size - r->pos) : 0;
         if (to_read > est) to_read = est;
         int parts = agx_host_threads_c();
+        if (r->threads && parts > r->threads) parts = r->threads;
         if ((size_t)parts > to_read / ((size_t)4 << 20)) parts = (int)(to_read / ((size_t)4 << 20));
         if (want > 0 && parts > 1) {
             sw_scan j;

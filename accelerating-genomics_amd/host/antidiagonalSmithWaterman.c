@@ -130,6 +130,7 @@ int main(int argc, char *argv[])
         fprintf(stderr, "%s\n", agx_last_error()); /* perror("Error opening file"), :196-199 */
         exit(EXIT_FAILURE);
     }
+    if (getenv("AGX_CLI_PARSE_THREADS")) agx_sw_reader_set_threads(ps.reader, atoi(getenv("AGX_CLI_PARSE_THREADS")));
     agx_pipe_init(&ps.q, 2);
     print_stage pr;
     memset(&pr, 0, sizeof pr);

@@ -291,6 +291,9 @@ void agx_sw_text_free(agx_sw_text *t);
 typedef struct agx_sw_reader agx_sw_reader;
 int agx_sw_reader_open(const char *path, int line_buf, agx_sw_reader **out);
 int32_t agx_sw_reader_line_num(const agx_sw_reader *r);
+/* how many host threads read and scan a chunk of a regular file (default 0 = the library's thread pool; 1 = the
+ * calling thread alone) */
+void agx_sw_reader_set_threads(agx_sw_reader *r, int n_threads);
 int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out);
 int agx_sw_reader_done(const agx_sw_reader *r);
 void agx_sw_reader_close(agx_sw_reader *r);
