@@ -309,6 +309,12 @@ def main():
         c5_t = timed(c5_dev, lambda: c5_dev.results(c5_out, want_sums=False), *few())
         c5_sum = float(c5_out[0].sum())
         c5_dev.close()
+        # the same shard with explicit fma (AGX_PHMM_F64_FMA): inside the tolerance config 5 states (1e-12), not bit-identical
+        c5m_out = (agx.host_array(c5.n_pairs, np.float64), None)
+        c5m_dev = ctx.phmm_batch(c5, agx.PHMM_F64_FMA)
+        c5m_t = timed(c5m_dev, lambda: c5m_dev.results(c5m_out, want_sums=False), *few())
+        c5m_dev.close()
+        c5m_rel = float(np.max(np.abs(c5m_out[0] - c5_out[0]) / np.maximum(np.abs(c5_out[0]), 1e-300)))
 
         # ---------------- strong legs: ONE host batch of the full size, the same on every rank, cut by cells
         def per_rank_table(pairs, cells, t):
@@ -442,7 +448,10 @@ def main():
                               log10_checksum=c5_sum, roofline=roof(c5.algorithmic_bytes(), c5_t["launch_ms"], None),
                               total=dict(strong(s5_t, s5_rows, c5f.n_pairs, "pairs/s", "cells"),
                                          workload="ONE batch of 262 144 pairs R=250 H=500 (512 regions) cut into %d shards of whole regions by cells (agx_phmm_shard_cuts)" % world),
-                              per_rank=s5_rows)
+                              per_rank=s5_rows,
+                              fp64_fma=dict(leg(c5m_t, c5.n_pairs, "pairs_per_s"), unit="pairs/s",
+                                            what="the weak leg's shard with explicit fma (AGX_PHMM_F64_FMA): 8 instead of 11 fp64 operations per cell",
+                                            max_rel_diff_to_bit_identical=c5m_rel, tolerance_asked=1e-12))
         out["multi_one_process"] = multi_one
         out["one_shot"] = one
     if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
