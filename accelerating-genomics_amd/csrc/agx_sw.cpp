@@ -739,7 +739,10 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         double waves_est = 0;
         for (const Worker &w : wk) waves_est += w.waves;
         const double fill = waves_est / (5.0 * 4.0 * n_cu);
-        if (fill < 1.6) {
+        // (the biased packed fill runs two waves per SIMD, and with its round-2b cell the term pays up to 1.2 of ITS
+        // fillings = 0.48 of these: 45 056 mixed pairs 6.5 -> 7.2 TCUPS, 49 152 7.15 -> 7.26, but 57 344 7.74 -> 7.55 and
+        // 65 536 8.07 -> 7.71 -- tools/sw_tail_rule_check.py)
+        if (fill < (family == 2 ? 0.48 : 1.6)) {
             beta_used = fill < 0.1 ? 10.0 : fill < 0.4 ? 6.0 : 3.0;
             tile_all(~0u, beta_used, false);
         }
