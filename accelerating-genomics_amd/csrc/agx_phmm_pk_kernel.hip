@@ -24,7 +24,11 @@
 //     v_perm_b32(0, T, sel) is 0x3f000000 = 0.5f where haplotype a matches, v_perm_b32(T', 0, sel) with
 //     T' = (T & 0x01010101) << 7 is 0x00800000 = 2^-126 where b does, and prior = fma({0.5, 2^-126} or 0,
 //     {2 (pm - pq), 2^126 (pm - pq)}, pq) -- three instructions where two compares and two selects stood.
-// = 10 packed/perm instructions per 2 cells against 12.
+//   * M is stored times the row's D = Qd gm+, the factor the Y chain multiplies it with (1 in the last row, whose Y
+//     nobody reads, so the final sum sees the true M): Y' = fma(Y'_left, Qg, M_left) needs no product, the factor
+//     folds into the priors and, through the previous row's D, out of the other two uses of M (row constants
+//     mm / D-, Qi gm+ / D-).
+// = 9 packed/perm instructions per 2 cells against 12.
 //
 // Numerics: float with the initial constant FLT_MAX/16 like AGX_PHMM_F32, but contracted -- not
 // bit-identical to the oracle's float restatement; the bar is BASELINE config 3's 1e-6 relative on
@@ -91,7 +95,8 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
     // operations p()/mm() prescribe (:111-117), done once per row here instead of once per lane and
     // step; a lane fetches its row with two ds_read_b128 from one address.  Neutral rows (before
     // the read and behind it): priors irrelevant, mm = 1, 1-Qg = 0, Qi = Qd = 0, Qg = 1.
-    // FAST: {mismatch prior pq, 2 (pm - pq), 1-(Qi+Qd), Qi gm+ | Qg gm+ / gm, Qd gm+, Qg, T}, gm of a row before the read =
+    // FAST: {pq D, 2 (pm - pq) D, (1-(Qi+Qd)) / D-, Qi gm+ / D- | Qg gm+ / gm, -, Qg, T} (D = Qd gm+ of this row, D- of the
+    // previous one; see below), gm of a row before the read =
     // the first row's, behind it = 1, and both priors of a neutral row 0 (neutral rows then keep the scaled state as it is).
     const uint32_t rows = w.steps + (uint32_t)G - 1u;
     const size_t tab_bytes = ph_pk_tab_bytes(rows);
@@ -120,12 +125,23 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
                     return 1 - lut[rp[4 * trk + (k < 0 ? 0 : k)]];
                 };
                 const double g = gm_of(i), gp = gm_of(i + 1);
+                // M is carried times this row's D = Qd gm+ (what the Y chain multiplies it with), except in the last row,
+                // whose Y nobody reads: D = 1 there, so the final sum sees the true M.  The factor folds into the priors
+                // (M_stored = (prior D) * u) and out of the two other uses of M through the previous row's D.
+                auto d_of = [&](int k) -> double { // D of read row k; 1 outside the read and in its last row
+                    if (k < 0 || k >= (int)tb.R - 1) return 1.0;
+                    return (double)lut[rp[3 * trk + k]] * (double)gm_of(k + 1);
+                };
+                const double dcur = d_of(i), dprev = d_of(i - 1);
                 // (a neutral row's priors are BOTH zero here: the plain cell's neutral rows keep M = 0 through gm = 0,
                 // which this cell no longer multiplies with -- a haplotype N would match the row and pick 1 - Qr = 1)
                 const bool real = i >= 0 && i < (int)tb.R;
+                // (the prior starts from the MISMATCH value and a match adds pm - pq: the other way round -- matches exact,
+                // mismatches pm - (pm - pq) -- cancels: errors of 1e-4 in log10 L, measured)
                 const uint32_t tbl = !real ? 0u : c == (uint32_t)'N' ? 0x3f3f3f3fu : 0x3fu << (8u * ((c >> 1) & 3u));
-                tr[2 * r] = float4{real ? pq : 0.f, real ? 2 * (pm - pq) : 0.f, 1 - (vi + vd), (float)((double)vi * gp)};
-                tr[2 * r + 1] = float4{(float)((double)vg * gp / g), (float)((double)vd * gp), vg, __uint_as_float(tbl)};
+                tr[2 * r] = float4{real ? (float)((double)pq * dcur) : 0.f, real ? (float)(2 * ((double)pm - (double)pq) * dcur) : 0.f,
+                                   (float)((1 - ((double)vi + (double)vd)) / dprev), (float)((double)vi * gp / dprev)};
+                tr[2 * r + 1] = float4{(float)((double)vg * gp / g), 0.f, vg, __uint_as_float(tbl)};
             } else {
                 tr[2 * r] = float4{pm, pq, 1 - (vi + vd), 1 - vg}; // mm() (:115-117)
                 tr[2 * r + 1] = float4{vi, vd, vg, __uint_as_float(c)};
@@ -197,7 +213,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             const float4 ra = trow[2 * t], rb = trow[2 * t + 1];
             const float pm = ra.x, pq = ra.y;
             const uint32_t rc = __float_as_uint(rb.w);
-            // plain: {pm, pq, mm, gm | Qi, Qd, Qg, base};  FAST: {pq, 2 (pm - pq), mm, Qi gm+ | Qg gm+ / gm, Qd gm+, Qg, T}
+            // plain: {pm, pq, mm, gm | Qi, Qd, Qg, base};  FAST: {pq D, 2 (pm - pq) D, mm / D-, Qi gm+ / D- | Qg gm+ / gm, -, Qg, T}
             const f2 mm = splat(ra.z), gm = splat(ra.w);
             const f2 qi = splat(FAST ? ra.w : rb.x), qd = splat(rb.y), qg = splat(rb.z);
             const f2 qx = splat(FAST ? rb.x : rb.z); // what X_up is multiplied with
@@ -250,13 +266,24 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             // the chain, so only one fused multiply-add per column sits on it (mul + fma, both on the chain, took
             // twice the latency per column and half of the loop's hazard nops).
             f2 cY = lY;
-            f2 a[3] = {lM * qd, M[0] * qd, C > 1 ? M[C > 1 ? 1 : 0] * qd : splat(0.f)}; // products run three columns ahead of the chain
+            if constexpr (FAST) { // M is stored times Qd gm+ already: one fused multiply-add per column, nothing else
+                f2 cM = lM;
 #pragma unroll
-            for (int j = 0; j < C; ++j) {
-                const f2 y = fma2(cY, qg, a[j % 3]);
-                if (j + 3 < C + 1) a[j % 3] = M[j + 2 < C ? j + 2 : C - 1] * qd;
-                cY = y;
-                Y[j] = y;
+                for (int j = 0; j < C; ++j) {
+                    const f2 y = fma2(cY, qg, cM);
+                    cM = M[j];
+                    cY = y;
+                    Y[j] = y;
+                }
+            } else {
+                f2 a[3] = {lM * qd, M[0] * qd, C > 1 ? M[C > 1 ? 1 : 0] * qd : splat(0.f)}; // products run three columns ahead of the chain
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    const f2 y = fma2(cY, qg, a[j % 3]);
+                    if (j + 3 < C + 1) a[j % 3] = M[j + 2 < C ? j + 2 : C - 1] * qd;
+                    cY = y;
+                    Y[j] = y;
+                }
             }
             if (t - gl + 1 == R) { // last read row: likelihood (:206-212)
                 // This block runs once per lane position (G times per wave, a few lanes each), so it is
