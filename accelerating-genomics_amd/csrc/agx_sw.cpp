@@ -241,7 +241,7 @@ struct agx_sw_batch {
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
     DevBuf table; // substitution-matrix mode: kSwMatDim^2 int16 entries
-    bool rising = false; // biased packed fill: the variant whose stored values rise by |ge| per step (agx_sw_pk2_kernel.hip, RISE)
+    int rising = 0; // biased packed fill: 1 = stored values rise by |ge| per step, 4 = and by |ge| per column in classes of four (agx_sw_pk2_kernel.hip, KC)
     PinBuf out_stage; // page-locked landing block of the scores, taken at create: agx_sw_batch_scores allocates nothing
                       // (a first hipHostMalloc costs milliseconds, and hipvers' timed window is launch -> scores)
     bool matrix = false;
@@ -478,9 +478,11 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (matrix || longest_short > (uint32_t)kSwPackedMaxShort) family = 0; // the matrix lookup exists in the int32 kernel only
     if (family == 2 && !((int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00)) family = 1;
     // ... and its rising-offset variant adds (steps + 2) |ge| on top, steps <= longest longer side + 63
-    bool rising = family == 2 &&
-                  (int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf + ((int64_t)longest_long + 66) * -(int64_t)prm.ge < 0x7c00;
-    if (const char *e = agx_tune("AGX_SW_RISE")) rising = rising && e[0] != '0';
+    int rising = family == 2 &&
+                 (int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf + ((int64_t)longest_long + 66 + 3) * -(int64_t)prm.ge < 0x7c00;
+    // ... with column classes when the wrapping column's diagonal constant, mismatch + |gf| - 3 |ge|, is not negative
+    if (rising && prm.hd - prm.delta + 3 * prm.ge >= 0) rising = 4;
+    if (const char *e = agx_tune("AGX_SW_RISE")) rising = e[0] == '0' ? 0 : e[0] == '1' && rising ? 1 : rising;
     const bool packed = family != 0;
     const double *costs = class_costs(family);
     const int slots = packed ? 2 : 1;

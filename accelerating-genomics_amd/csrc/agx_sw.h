@@ -87,13 +87,13 @@ int agx_sw_pack_dna_launch(const uint8_t *raw, const uint64_t *off, uint64_t bas
                            uint32_t n_pairs, uint32_t *img, uint32_t *flag, int n_cu, hipStream_t s);
 int agx_sw_pk_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                            const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
-int agx_sw_pk2_launch_class(int cols_per_lane, bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+int agx_sw_pk2_launch_class(int cols_per_lane, int rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 // every class of a mixed batch in one launch: waves[].reserved holds each wave's columns per lane
 void agx_sw_pk2_preload();
 void agx_sw_pack_preload();
 void agx_sw_i32_preload();
-int agx_sw_pk2_launch_any(bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+int agx_sw_pk2_launch_any(int rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
                           int32_t *scores, hipStream_t s);
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);

@@ -139,21 +139,37 @@ __device__ __forceinline__ void bytes_head(uint32_t &zl, uint32_t &fl, uint32_t 
 // gap's subtraction (max(z_left + |ge|, f_left + |ge|) - |ge|), and the diagonal adds |ge| through its constant.
 // The host asks for this variant when B + the largest score + (steps + 2) |ge| stays
 // below 0x7c00 (agx_sw.cpp) -- rows up to about 27 000 with the reference's scores; beyond, the plain cell.
-template <int C, bool FAST, bool RISE>
+//
+// KC = column classes of the rising cell (0: plain cell, 1: rising, 4: rising with classes).  With KC = 4 column j of a
+// lane additionally carries (j mod 4) |ge|: from one column to the next the offset rises by |ge|, which is exactly what
+// the horizontal gap subtracts -- f = max(z_left, f) with no subtraction, except where the class wraps (every fourth
+// column: minus 4 |ge|) -- and the diagonal adds |ge| through its constant (minus 3 |ge| at a wrap: the host asks for
+// this variant only when mismatch + |gf| >= 3 |ge|, so that constant is not negative).  The floor and the running
+// maximum exist once per class (each rises by |ge| per step; a class's maximum takes its columns two at a time), what a
+// lane hands to its right neighbour loses the last column's class offset on arrival, and the classes' maxima are
+// brought to one offset at the end.  Per column (two cells) 6 + 1/4 + 1/2 instructions and ten per step, against
+// 7 + 1/2 and two.
+template <int C, bool FAST, int KC>
 __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 &g, const SwWave &w,
                                          int32_t *__restrict__ scores, int lane, int G, int gl, bool active, bool start, bool feeder)
 {
     constexpr int XW = (C + 3) / 4; // dwords holding this lane's C symbols
+    constexpr bool RISE = KC > 0;
+    constexpr int NK = KC > 1 ? KC : 1;               // floors / running maxima kept
+    constexpr int kEnd = KC > 1 ? (C - 1) % KC : 0;   // class of the lane's last column
     const uint32_t sh_sym = prm.shift;         // general: symbols live as byte << shift
     const uint32_t col_pad = 0x100u << sh_sym; // never equals (byte << shift)
     const uint32_t ge = in_vgpr(prm.age2), gf = in_vgpr(RISE ? prm.agf2 - prm.age2 : prm.agf2); // |ge|; |gf| (RISE: |gf| - |ge|)
     const uint32_t hd = in_vgpr(FAST ? prm.hd2 - prm.delta2 : prm.hd2);                // mismatch + |gf| / match + |gf|
     const uint32_t bias = prm.bias2, delta = prm.delta2;
     const uint32_t z0 = prm.bias2 - prm.agf2; // H = 0 as the state both gap recurrences read (z = H + gf), both halves
-    const uint32_t hd0 = in_vgpr((FAST ? prm.hd2 - prm.delta2 : prm.hd2) + (RISE ? prm.age2 : 0u)); // first column's diagonal
-    uint32_t zb = RISE ? z0 + prm.age2 : z0;                      // column 0 as the first lane takes it over: z0 + r(t - 1)
-    uint32_t floorv = in_vgpr(RISE ? bias + prm.age2 : bias);     // P~ >= 0 at H's offset: B + r(t - 1); in a VGPR: as an
-                                                                  // SGPR operand it drew an s_nop after every group of four
+    const uint32_t hd0 = in_vgpr((FAST ? prm.hd2 - prm.delta2 : prm.hd2) + (RISE ? prm.age2 : 0u)); // first column's diagonal; KC > 1: every non-wrapping one's
+    const uint32_t hdw = in_vgpr((FAST ? prm.hd2 - prm.delta2 : prm.hd2) + prm.age2 - (uint32_t)NK * prm.age2); // KC > 1: a wrapping column's diagonal
+    const uint32_t ge_wrap = in_vgpr((uint32_t)NK * prm.age2), c_end = in_vgpr((uint32_t)kEnd * prm.age2);
+    uint32_t zb = (RISE ? z0 + prm.age2 : z0) + (uint32_t)kEnd * prm.age2; // column 0 as the first lane takes it over: z0 + r(t - 1) (+ what every lane takes off on arrival)
+    uint32_t floorv[NK];                                          // P~ >= 0 at H's offset: B + r(t - 1) (+ class); in VGPRs: as an
+#pragma unroll                                                    // SGPR operand it drew an s_nop after every group of four
+    for (int k = 0; k < NK; ++k) floorv[k] = in_vgpr((RISE ? bias + prm.age2 : bias) + (uint32_t)k * prm.age2);
     const uint32_t z_init = RISE ? z0 + prm.age2 : z0;            // H = 0 one step before the first: z0 + r(-1)
     const uint32_t kv = in_vgpr((prm.delta2 & 0xffu) << 24); // FAST: the table source
     const uint64_t start_mask = __ballot(start);
@@ -208,12 +224,15 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     uint32_t z[C], e[C];
 #pragma unroll
     for (int j = 0; j < C; ++j) {
-        z[j] = z_init;
-        e[j] = bias; // anything up to the first floor
+        z[j] = z_init + (uint32_t)(j % NK) * prm.age2;
+        e[j] = bias + (uint32_t)(j % NK) * prm.age2; // anything up to the first floor
     }
     // the horizontal gap state needs no clamp: Q >= z_left >= gf always; "no gap open yet" is Q = gf,
     // whose successor gf + ge loses against every z_left
-    uint32_t z_last = z_init, f_last = z_init, diag_in = z0, best = z_init;
+    uint32_t z_last = z_init + (uint32_t)kEnd * prm.age2, f_last = z_last, diag_in = z0;
+    uint32_t best[NK]; // :335, one per class
+#pragma unroll
+    for (int k = 0; k < NK; ++k) best[k] = z_init + (uint32_t)k * prm.age2;
     uint32_t yc = 0;         // general: the row symbols of both pairs
     uint32_t ta = 0, tb = 0; // FAST: the row tables of pair A / pair B
 
@@ -222,7 +241,7 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     const bool last = active && gl == G - 1;
     const bool nlA = FAST && last && ((g.lx_ly[0] >> 13) & 1u), nlB = FAST && last && ((g.lx_ly[1] >> 13) & 1u);
     const int capA_t = (nlA && lxA > 0 && lyA > 0) ? lyA + G - 2 : -1, capB_t = (nlB && lxB > 0 && lyB > 0) ? lyB + G - 2 : -1;
-    uint32_t cornerA = z_init, cornerB = z_init;
+    uint32_t cornerA = z_init + (uint32_t)kEnd * prm.age2, cornerB = cornerA; // (taken from the last column: its class offset comes off at the end)
 
     uint32_t a0 = quadA(0), a1 = quadA(1), a2 = quadA(2);
     uint32_t b0 = quadB(0), b1 = quadB(1), b2 = quadB(2);
@@ -238,38 +257,54 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
             fast_head<K>(zl, fl, ta, tb, rowsA, rowsB, kv, start_mask, z_last, f_last, zb);
         else
             bytes_head(zl, fl, yc, rowsA, rowsB, 0x0c040c00u + 0x00010001u * K, sh_sym, start_mask, z_last, f_last, zb);
-        if constexpr (RISE) best += ge;
+        if constexpr (KC > 1 && kEnd > 0) { // what the left neighbour's last column carried for its class comes off
+            zl -= c_end;
+            fl -= c_end;
+        }
+        if constexpr (RISE) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) best[k] += ge;
+        }
         uint32_t zd = diag_in; // H[r-1][first column - 1] + gf
         diag_in = zl;
         uint32_t zleft = zl, f = fl;
 #pragma unroll
-        for (int j = 0; j < C; j += 2) {
-            uint32_t zn[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint32_t up = z[j + k];
-                uint32_t ev; // reference P, :313, clamped at 0;  reference Q, :321
-                if constexpr (RISE) {
-                    ev = umax3(up, e[j + k], floorv);
-                    f = umax2(zleft, f);
-                    if (j + k > 0) f -= ge; // (first column: see above)
-                } else {
-                    ev = umax3(up, e[j + k] - ge, bias);
-                    f = umax2(zleft, f - ge);
-                }
-                uint32_t u;                                        // H_diag + match / + mismatch, :332
-                if constexpr (FAST)
-                    u = (zd + (j + k ? hd : hd0)) + __builtin_amdgcn_perm(tb, ta, xq[j + k]); // mismatch, plus delta on a match
-                else
-                    u = (zd + (j + k ? hd : hd0)) - umin2(xq[j + k] ^ yc, delta); // match, minus delta on a mismatch
-                const uint32_t v = umax3(ev, f, u);                // :333 (ev >= B carries the zero floor)
-                zn[k] = v - gf;
-                e[j + k] = ev;
-                z[j + k] = zn[k];
-                zd = up;
-                zleft = zn[k];
+        for (int j = 0; j < C; ++j) {
+            const bool wrap = KC > 1 && j > 0 && j % NK == 0; // compile-time after unrolling
+            const uint32_t up = z[j];
+            uint32_t ev; // reference P, :313, clamped at 0;  reference Q, :321
+            if constexpr (RISE) {
+                ev = umax3(up, e[j], floorv[j % NK]);
+                f = umax2(zleft, f);
+                if (KC == 1 && j > 0) f -= ge; // (first column: see above)
+                if (wrap) f -= ge_wrap;
+            } else {
+                ev = umax3(up, e[j] - ge, bias);
+                f = umax2(zleft, f - ge);
             }
-            best = umax3(best, zn[0], zn[1]); // :335
+            const uint32_t hdc = KC > 1 ? (wrap ? hdw : hd0) : (j ? hd : hd0);
+            uint32_t u;                                        // H_diag + match / + mismatch, :332
+            if constexpr (FAST)
+                u = (zd + hdc) + __builtin_amdgcn_perm(tb, ta, xq[j]); // mismatch, plus delta on a match
+            else
+                u = (zd + hdc) - umin2(xq[j] ^ yc, delta); // match, minus delta on a mismatch
+            const uint32_t v = umax3(ev, f, u);                // :333 (ev >= B carries the zero floor)
+            const uint32_t zn = v - gf;
+            e[j] = ev;
+            z[j] = zn;
+            zd = up;
+            zleft = zn;
+        }
+        // :335 -- every class's maximum takes that class's columns two at a time
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+            for (int j = k; j < C; j += 2 * NK) {
+                if (j + NK < C)
+                    best[k] = umax3(best[k], z[j], z[j + NK]);
+                else
+                    best[k] = umax2(best[k], z[j]);
+            }
         }
         if constexpr (FAST) {
             cornerA = t == capA_t ? zleft : cornerA;
@@ -278,7 +313,8 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         z_last = zleft;
         f_last = f;
         if constexpr (RISE) {
-            floorv += ge;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) floorv[k] += ge;
             zb += prm.age2;
         }
         ++t;
@@ -313,24 +349,28 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         // H_corner + match as a z value is z_corner + match.
         const uint32_t match2 = prm.hd2 - prm.agf2; // (match + |gf|) - |gf| in both halves
         const uint32_t ge1 = RISE ? prm.age2 & 0xffffu : 0u; // the corner was taken at offset r(cap_t), best stands at r(steps - 1)
-        uint32_t cand = best;
-        if (nlA) cand = (cand & 0xffff0000u) | ((cornerA + match2 + (uint32_t)(steps - 1 - capA_t) * ge1) & 0xffffu);
-        if (nlB) cand = (cand & 0xffffu) | ((cornerB + match2 + ((uint32_t)(steps - 1 - capB_t) * ge1 << 16)) & 0xffff0000u);
-        best = umax2(best, cand);
+        const uint32_t off_end = (uint32_t)kEnd * (prm.age2 & 0xffffu);
+        uint32_t cand = best[0];
+        if (nlA) cand = (cand & 0xffff0000u) | ((cornerA + match2 + (uint32_t)(steps - 1 - capA_t) * ge1 - off_end) & 0xffffu);
+        if (nlB) cand = (cand & 0xffffu) | ((cornerB + match2 + (((uint32_t)(steps - 1 - capB_t) * ge1 - off_end) << 16)) & 0xffff0000u);
+        best[0] = umax2(best[0], cand);
     }
+#pragma unroll
+    for (int k = 1; k < NK; ++k) best[0] = umax2(best[0], best[k] - (uint32_t)k * prm.age2); // the classes at one offset
+    uint32_t bestv = best[0];
     // max over the group's lanes (G need not be a power of two), both halves at once
     for (int o = 1; o < G; o <<= 1) {
-        const uint32_t other = (uint32_t)__shfl_down((int)best, o);
-        if (gl + o < G) best = umax2(best, other);
+        const uint32_t other = (uint32_t)__shfl_down((int)bestv, o);
+        if (gl + o < G) bestv = umax2(bestv, other);
     }
     if (feeder) {
         const int off = (int)(z0 & 0xffffu) + (RISE ? (steps + 1) * (int)(prm.age2 & 0xffffu) : 0); // stored value of H = 0, at r(steps - 1)
-        scores[g.out[0]] = (int)(best & 0xffffu) - off;
-        scores[g.out[1]] = (int)(best >> 16) - off; // a group without a second pair points this at the spare slot
+        scores[g.out[0]] = (int)(bestv & 0xffffu) - off;
+        scores[g.out[1]] = (int)(bestv >> 16) - off; // a group without a second pair points this at the spare slot
     }
 }
 
-template <int C, bool RISE>
+template <int C, int KC>
 __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__restrict__ img, const SwGroup2 *__restrict__ groups,
                                          const SwWave w, int32_t *__restrict__ scores)
 {
@@ -349,12 +389,12 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
     if (active) g = groups[w.first_group + grp];
     // bit 16 of the wave record's class word: set by the pack kernel when every pair of the wave is DNA-coded
     if (__builtin_amdgcn_readfirstlane(w.reserved >> 16) & 1u)
-        pk2_fill<C, true, RISE>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, true, KC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
     else
-        pk2_fill<C, false, RISE>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, false, KC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
 }
 
-template <int C, bool RISE>
+template <int C, int KC>
 __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uint32_t *__restrict__ img,
                                                    const SwGroup2 *__restrict__ groups,
                                                    const SwWave *__restrict__ waves, uint32_t n_waves,
@@ -362,7 +402,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (wave >= n_waves) return;
-    pk2_body<C, RISE>(prm, img, groups, waves[wave], scores);
+    pk2_body<C, KC>(prm, img, groups, waves[wave], scores);
 }
 
 // Mixed batches: ONE launch for every lane-tiling class.  Each wavefront reads its class (columns per lane)
@@ -370,7 +410,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 // (100 VGPRs, five waves per SIMD -- the fill is bound by VALU issue, not by occupancy).  Against one launch
 // per class this (a) lets the planner use every width, so padding shrinks, (b) dispatches the waves of ALL
 // classes longest first, (c) has no stream fork/join and no per-launch ramp.
-template <bool RISE>
+template <int KC>
 __global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const uint32_t *__restrict__ img,
                                                        const SwGroup2 *__restrict__ groups,
                                                        const SwWave *__restrict__ waves, uint32_t n_waves,
@@ -381,43 +421,45 @@ __global__ void __launch_bounds__(256) sw_fill_pk2_any(const SwParams prm, const
     const SwWave w = waves[wave];
     switch (__builtin_amdgcn_readfirstlane(w.reserved) & 0xffffu) { // columns per lane of this wave
 #define AGX_SW_CASE(CC) \
-    case CC: pk2_body<CC, RISE>(prm, img, groups, w, scores); break;
+    case CC: pk2_body<CC, KC>(prm, img, groups, w, scores); break;
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: break;
     }
 }
 
-template <int C, bool RISE>
+template <int C, int KC>
 int launch(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
            int32_t *scores, hipStream_t s)
 {
     const uint32_t blocks = (n_waves + 3) / 4;
-    hipLaunchKernelGGL((sw_fill_pk2<C, RISE>), dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    hipLaunchKernelGGL((sw_fill_pk2<C, KC>), dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 } // namespace
 
-int agx_sw_pk2_launch_any(bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
+int agx_sw_pk2_launch_any(int rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
                           int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     const uint32_t blocks = (n_waves + 3) / 4;
-    if (rising)
-        hipLaunchKernelGGL(sw_fill_pk2_any<true>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    if (rising == 4)
+        hipLaunchKernelGGL(sw_fill_pk2_any<4>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+    else if (rising)
+        hipLaunchKernelGGL(sw_fill_pk2_any<1>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     else
-        hipLaunchKernelGGL(sw_fill_pk2_any<false>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
+        hipLaunchKernelGGL(sw_fill_pk2_any<0>, dim3(blocks), dim3(256), 0, s, prm, img, groups, waves, n_waves, scores);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int agx_sw_pk2_launch_class(int cols_per_lane, bool rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
+int agx_sw_pk2_launch_class(int cols_per_lane, int rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups,
                             const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     switch (cols_per_lane) {
 #define AGX_SW_CASE(CC) \
-    case CC: return rising ? launch<CC, true>(prm, img, groups, waves, n_waves, scores, s) : launch<CC, false>(prm, img, groups, waves, n_waves, scores, s);
+    case CC: return rising == 4 ? launch<CC, 4>(prm, img, groups, waves, n_waves, scores, s) : rising ? launch<CC, 1>(prm, img, groups, waves, n_waves, scores, s) : launch<CC, 0>(prm, img, groups, waves, n_waves, scores, s);
         AGX_SW_FOR_EACH_CLASS(AGX_SW_CASE)
 #undef AGX_SW_CASE
     default: return -2;
@@ -429,5 +471,5 @@ int agx_sw_pk2_launch_class(int cols_per_lane, bool rising, const SwParams &prm,
 void agx_sw_pk2_preload()
 {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_fill_pk2_any<true>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&sw_fill_pk2_any<4>));
 }
