@@ -66,9 +66,9 @@ static const int kSwNumClasses = sizeof(kSwClasses) / sizeof(kSwClasses[0]);
 static const double kSwClassCost[] = {1.373, 1.250, 1.178, 1.138, 1.112, 1.080, 1.051, 1.033, 1.025, 1.022, 1.014, 1.014, 1.011, 1.007, 1.007, 1.004, 1.004, 1.004, 1.000, 1.6, 2.2, 4.0};
 // same for the packed int16 kernel
 static const double kSwPkClassCost[] = {1.543, 1.358, 1.278, 1.210, 1.173, 1.136, 1.111, 1.086, 1.068, 1.037, 1.025, 1.025, 1.019, 1.012, 1.006, 1.006, 1.006, 1.000, 1.000, 0, 0, 0}; // 0 = not built
-// and for its biased formulation (agx_sw_pk2_kernel.hip, the DNA-coded rising-offset cell; tools/cal_sw_pk.py,
-// profiles/r02b_cal_sw_pk2.log: 0.1024 ps per padded cell at 40 columns)
-static const double kSwPk2ClassCost[] = {1.803, 1.520, 1.353, 1.305, 1.255, 1.201, 1.168, 1.149, 1.124, 1.083, 1.053, 1.047, 1.034, 1.025, 1.022, 1.016, 1.000, 1.004, 1.000, 0, 0, 0};
+// and for its biased formulation (agx_sw_pk2_kernel.hip, the DNA-coded rising cell with column classes; tools/cal_sw_pk.py,
+// profiles/r02h_cal_sw_pk2.log: 0.0951 ps per padded cell at 40 columns)
+static const double kSwPk2ClassCost[] = {1.851, 1.581, 1.450, 1.367, 1.318, 1.263, 1.196, 1.184, 1.145, 1.097, 1.095, 1.056, 1.049, 1.053, 1.025, 1.023, 1.022, 1.016, 1.000, 0, 0, 0};
 
 // substitution-matrix mode: symbol numbers 1..32 in the image, 0 = padding; the device table is
 // kSwMatDim x kSwMatDim int16 entries score - (gap_open + gap_extend)

@@ -375,6 +375,8 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
                                          const SwWave w, int32_t *__restrict__ scores)
 {
     static_assert(C % 2 == 0, "the running maximum takes two columns per instruction");
+    // column classes cost ten instructions a step and save three quarters of one per column: narrow lanes do without
+    constexpr int KCC = KC > 1 && C < 14 ? 1 : KC;
     const int lane = threadIdx.x & 63;
     const int G = w.G;
     const int grp = lane / G;
@@ -389,9 +391,9 @@ __device__ __forceinline__ void pk2_body(const SwParams &prm, const uint32_t *__
     if (active) g = groups[w.first_group + grp];
     // bit 16 of the wave record's class word: set by the pack kernel when every pair of the wave is DNA-coded
     if (__builtin_amdgcn_readfirstlane(w.reserved >> 16) & 1u)
-        pk2_fill<C, true, KC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, true, KCC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
     else
-        pk2_fill<C, false, KC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
+        pk2_fill<C, false, KCC>(prm, img, g, w, scores, lane, G, gl, active, start, feeder);
 }
 
 template <int C, int KC>
