@@ -319,8 +319,9 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
         };
         int t = 0;
         // (only the builds with registers to spare: the plain cell at widths 19, 31, 32 sits at its cap and spills 40-100
-        // values when two steps are in flight)
-        if constexpr (FAST && ROW16) {
+        // values when two steps are in flight; width 19's fast cell -- config 3, capped at 168 registers for three waves
+        // per SIMD -- spilled five and ran no faster than one step per trip without spills: 0.321-0.327 against 0.326 ms)
+        if constexpr (FAST && ROW16 && C != kPkThreeWaveWidth) {
             for (; t + 1 < steps; t += 2) {
                 one_step(t);
                 one_step(t + 1);
