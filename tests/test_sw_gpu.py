@@ -181,7 +181,7 @@ def test_largest_supported_shapes(ctx, oracle):
 
 
 @pytest.mark.parametrize("scoring", [(1, -1, -3, -1), (2, -3, -5, -2), (5, -4, -10, -1), (1, -3, 0, -2), (3, -1, -4, 0),
-                                     (12, -100, -50, -7), (2, 0, -1, -1)])
+                                     (12, -100, -50, -7), (2, 0, -1, -1), (3, -1, -10, -3), (4, -6, -2, -5)])
 def test_runtime_scoring_vs_parametrised_oracle(ctx, oracle, scoring):
     """8f n3.  Only (1,-1,-3,-1) is the reference's; the rest is pinned against the oracle's own Gotoh."""
     b = synth.sw_pairs(1500, 1, 400, seed=abs(sum(scoring)) + 50, related_frac=0.6)
