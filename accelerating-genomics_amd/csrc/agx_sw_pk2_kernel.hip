@@ -169,7 +169,7 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
     uint32_t zb = (RISE ? z0 + prm.age2 : z0) + (uint32_t)kEnd * prm.age2; // column 0 as the first lane takes it over: z0 + r(t - 1) (+ what every lane takes off on arrival)
     uint32_t floorv[NK];                                          // P~ >= 0 at H's offset: B + r(t - 1) (+ class); in VGPRs: as an
 #pragma unroll                                                    // SGPR operand it drew an s_nop after every group of four
-    for (int k = 0; k < NK; ++k) floorv[k] = in_vgpr((RISE ? bias + prm.age2 : bias) + (uint32_t)k * prm.age2);
+    for (int k = 0; k < NK; ++k) floorv[k] = (RISE ? bias + prm.age2 : bias) + (uint32_t)k * prm.age2;
     const uint32_t z_init = RISE ? z0 + prm.age2 : z0;            // H = 0 one step before the first: z0 + r(-1)
     const uint32_t kv = in_vgpr((prm.delta2 & 0xffu) << 24); // FAST: the table source
     const uint64_t start_mask = __ballot(start);
@@ -314,7 +314,7 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         f_last = f;
         if constexpr (RISE) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) floorv[k] += ge;
+            for (int k = 0; k < NK; ++k) floorv[k] += prm.age2;
             zb += prm.age2;
         }
         ++t;
