@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -183,6 +184,441 @@ void build_lut(bool gatk_prior, double *d, float *f, double *mis_d, float *mis_f
     }
 }
 
+// ---- a plan: lane tilings, waves and records for one kernel family
+struct PlanOut {
+    std::vector<PhGroup> groups1;
+    std::vector<PhGroup2> groups2;
+    std::vector<PhTab> tabs;
+    std::vector<PhWave> waves;
+    std::vector<ClassLaunch> launches;
+    int64_t padded = 0;
+};
+
+// What a plan is made from: the pairs with work in output order (region, read, haplotype) and where the image holds
+// every read and haplotype.  A packed float batch keeps it: its double rescue plan is made when a fill first counts a
+// pair below the float range (config 3: never), not at creation.
+struct PlanSeed {
+    std::vector<Plan> gen0;
+    std::vector<uint32_t> read_dw, hap_dw;
+    int64_t n_pairs = 0;
+    int n_cu = 256;
+    bool gatk_prior = false;
+};
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Cuts [0, n) into at most `parts` pieces of about equal size whose inner boundaries satisfy is_cut(i) (i starts a new
+// run): every O(pairs) pass of the planner that works run by run is threaded over such pieces.
+template <typename F>
+std::vector<size_t> cut_at_runs(size_t n, int parts, F is_cut)
+{
+    std::vector<size_t> cut{0};
+    for (int k = 1; k < parts; ++k) {
+        size_t i = std::max(cut.back(), n * (size_t)k / (size_t)parts);
+        while (i < n && (i == 0 || !is_cut(i))) ++i;
+        if (i > cut.back() && i < n) cut.push_back(i);
+    }
+    cut.push_back(n);
+    return cut;
+}
+
+// kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group; `gen` (a copy of
+// seed.gen0, or seed.gen0 itself when nobody needs it afterwards) is consumed.
+int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, bool rows_f64, bool trace, PlanOut &po)
+{
+    const double tm0 = now_ms();
+    double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
+    const ClassTable ct = class_table(kind);
+    const bool gatk_prior = seed.gatk_prior;
+    const int n_cu = seed.n_cu;
+    const std::vector<uint32_t> &read_dw = seed.read_dw, &hap_dw = seed.hap_dw;
+    const uint32_t vacant_out = (uint32_t)seed.n_pairs;
+    auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
+    const int64_t n = (int64_t)gen.size();
+    auto key_of = [](const Plan &p) { return p.R << 16 | p.th; };
+    // Two haplotypes share a lane group in the packed kernel: within every read's run, order the
+    // haplotypes by length and tile neighbours for the longer of the two, so that partners get the
+    // same class (mixed-length regions would otherwise leave most second slots vacant).
+    // (fixed-length input -- BASELINE configs 3 and 5 -- needs neither this pairing nor the sorts below: every
+    // key is equal, the enumeration order already is the order they would produce)
+    const int nthr = agx_host_threads();
+    struct Range {
+        uint32_t r_min = 0xffffffffu, r_max = 0, h_min = 0xffffffffu, h_max = 0;
+        char pad[48]; // one cache line per part
+    };
+    std::vector<Range> ranges((size_t)nthr);
+    agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int t) {
+        Range r;
+        for (int64_t k = lo; k < hi; ++k) {
+            Plan &p = gen[(size_t)k];
+            p.th = p.H;
+            r.r_min = std::min(r.r_min, p.R), r.r_max = std::max(r.r_max, p.R);
+            r.h_min = std::min(r.h_min, p.H), r.h_max = std::max(r.h_max, p.H);
+        }
+        ranges[(size_t)t] = r;
+    });
+    Range all;
+    for (const Range &r : ranges) {
+        all.r_min = std::min(all.r_min, r.r_min), all.r_max = std::max(all.r_max, r.r_max);
+        all.h_min = std::min(all.h_min, r.h_min), all.h_max = std::max(all.h_max, r.h_max);
+    }
+    const bool one_shape = n > 0 && all.r_min == all.r_max && all.h_min == all.h_max;
+    const int run_parts = (int)std::min<int64_t>(nthr, std::max<int64_t>(1, n / 8192));
+    if (slots == 2 && !one_shape) {
+        const std::vector<size_t> cut = cut_at_runs((size_t)n, run_parts, [&](size_t i) { return gen[i].read != gen[i - 1].read; });
+        agx_pool_run((int)cut.size() - 1, [&](int t) {
+            size_t a = cut[(size_t)t];
+            const size_t end = cut[(size_t)t + 1];
+            while (a < end) {
+                size_t z = a;
+                while (z < end && gen[z].read == gen[a].read) ++z;
+                std::stable_sort(gen.begin() + (ptrdiff_t)a, gen.begin() + (ptrdiff_t)z, [](const Plan &x, const Plan &y) { return x.H > y.H; });
+                for (size_t k = a; k < z; ++k) gen[k].th = gen[a + ((k - a) & ~(size_t)1)].H; // the pair's longer one
+                a = z;
+            }
+        });
+    }
+    // Tiling per (R, H) shape.  The per-class cost curve is flat over many widths, and every class
+    // is its own launch: a mixed batch first chooses freely, then keeps the few classes that carry
+    // most of the work and re-tiles the rest among them (a shape no kept class can span keeps its own).
+    // The shapes of a batch live in a window of read and haplotype lengths: they are counted in a dense table over
+    // that window (threads add to it directly) when it has at most 2^20 cells, else through a hash map.
+    const uint64_t win_r = n ? (uint64_t)all.r_max - all.r_min + 1 : 0, win_h = n ? (uint64_t)all.h_max - all.h_min + 1 : 0;
+    const bool dense = win_r * win_h <= ((uint64_t)1 << 20);
+    std::unordered_map<uint32_t, uint32_t> sparse_slot; // key -> slot (batches whose window is too wide)
+    auto slot_of = [&](uint32_t key) -> size_t {
+        if (dense) return (size_t)((key >> 16) - all.r_min) * (size_t)win_h + ((key & 0xffffu) - all.h_min);
+        return sparse_slot.find(key)->second;
+    };
+    std::vector<uint32_t> slot_count;        // pairs per slot
+    std::vector<uint16_t> slot_tile;         // cls << 8 | G
+    std::vector<uint32_t> shape_key, shape_slot; // the distinct shapes
+    if (one_shape) {
+        slot_count.assign(1, (uint32_t)n);
+        shape_key.push_back(key_of(gen[0]));
+        shape_slot.push_back(0);
+    } else if (dense) {
+        slot_count.assign((size_t)(win_r * win_h), 0);
+        agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int) {
+            uint32_t last = 0, run = 0; // consecutive pairs often share their shape
+            for (int64_t k = lo; k < hi; ++k) {
+                const uint32_t key = key_of(gen[(size_t)k]);
+                if (run && key == last) {
+                    ++run;
+                    continue;
+                }
+                if (run) __atomic_fetch_add(&slot_count[slot_of(last)], run, __ATOMIC_RELAXED);
+                last = key;
+                run = 1;
+            }
+            if (run) __atomic_fetch_add(&slot_count[slot_of(last)], run, __ATOMIC_RELAXED);
+        });
+        for (size_t sl = 0; sl < slot_count.size(); ++sl)
+            if (slot_count[sl]) {
+                shape_key.push_back((uint32_t)(all.r_min + sl / win_h) << 16 | (uint32_t)(all.h_min + sl % win_h));
+                shape_slot.push_back((uint32_t)sl);
+            }
+    } else {
+        for (const Plan &p : gen) {
+            const auto it = sparse_slot.emplace(key_of(p), (uint32_t)slot_count.size());
+            if (it.second) {
+                slot_count.push_back(0);
+                shape_key.push_back(key_of(p));
+                shape_slot.push_back(it.first->second);
+            }
+            ++slot_count[it.first->second];
+        }
+    }
+    slot_tile.assign(slot_count.size(), (uint16_t)0xff00);
+    const int64_t n_shapes = (int64_t)shape_key.size();
+    const uint64_t all_classes = ~0ull;
+    std::vector<double> class_work((size_t)ct.n, 0.0);
+    double waves_est = 0;
+    auto tile_all = [&](double beta) {
+        std::vector<std::vector<double>> work((size_t)nthr, std::vector<double>((size_t)ct.n + 1, 0.0)); // [ct.n]: waves
+        agx_parallel_for(n_shapes, 512, [&](int64_t lo, int64_t hi, int t) {
+            std::vector<double> &wk = work[(size_t)t];
+            for (int64_t k = lo; k < hi; ++k) {
+                const uint32_t key = shape_key[(size_t)k], cnt = slot_count[shape_slot[(size_t)k]];
+                uint8_t c = 255, G = 0;
+                double cost = 0;
+                choose_tiling(kind, key >> 16, key & 0xffffu, all_classes, &c, &G, &cost, beta);
+                slot_tile[shape_slot[(size_t)k]] = (uint16_t)(c << 8 | G);
+                if (c < ct.n) {
+                    wk[c] += cost * cnt;
+                    wk[(size_t)ct.n] += (double)cnt * G / 64.0 / slots;
+                }
+            }
+        });
+        std::fill(class_work.begin(), class_work.end(), 0.0);
+        waves_est = 0;
+        for (const auto &wk : work) {
+            for (int c = 0; c < ct.n; ++c) class_work[(size_t)c] += wk[(size_t)c];
+            waves_est += wk[(size_t)ct.n];
+        }
+    };
+    double beta = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
+    tm1 = now_ms();
+    tile_all(beta);
+    // Tail regime (as in the SW planner): a batch whose waves fill the chip's resident capacity (3 waves
+    // per SIMD for the packed kernel, 2 for the others) less than 1.6 times lasts as long as its longest
+    // waves; it is re-tiled with 2 lanes' worth of extra cost on a wave's own duration, which spreads
+    // pairs over more lanes.  Mixed regions (tools/phmm_tail_beta_sweep.py): 2048 pairs +27 % packed /
+    // +35 % double, 16 384 pairs +30 % / +3 %; beyond 1.6 fillings the term costs a few percent.
+    if (tail_beta_override() < 0 && n_cu > 0 && waves_est / ((slots == 2 ? 3.0 : 2.0) * 4.0 * n_cu) < 1.6) {
+        beta = 2.0;
+        tile_all(beta);
+    }
+    {
+        // small batches afford fewer launches: about one class per 16384 wavefronts of work
+        // (tools/phmm_classes_sweep.py: the count matters little, fewer is never worse by more than 3 %)
+        const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 16384.0));
+        int used = 0;
+        for (double wk : class_work) used += wk > 0;
+        if (used > k_max) {
+            std::vector<int> order((size_t)ct.n);
+            for (int k = 0; k < ct.n; ++k) order[(size_t)k] = k;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return class_work[(size_t)x] > class_work[(size_t)y]; });
+            uint64_t keep = 0;
+            for (int k = 0; k < k_max; ++k) keep |= 1ull << order[(size_t)k];
+            agx_parallel_for(n_shapes, 512, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t k = lo; k < hi; ++k) {
+                    uint16_t &v = slot_tile[shape_slot[(size_t)k]];
+                    if ((v >> 8) < 64 && ((keep >> (v >> 8)) & 1u)) continue;
+                    uint8_t c = 255, G = 0;
+                    choose_tiling(kind, shape_key[(size_t)k] >> 16, shape_key[(size_t)k] & 0xffffu, keep, &c, &G, nullptr, beta);
+                    if (c < ct.n) v = (uint16_t)(c << 8 | G);
+                }
+            });
+        }
+    }
+    tm2 = now_ms();
+    {
+        std::atomic<int64_t> unfit{-1};
+        agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int) {
+            uint32_t last_key = 0;
+            uint16_t last_v = 0;
+            bool have = false;
+            for (int64_t gi = lo; gi < hi; ++gi) {
+                Plan &p = gen[(size_t)gi];
+                const uint32_t key = key_of(p);
+                if (!have || key != last_key) {
+                    last_v = slot_tile[one_shape ? 0 : slot_of(key)];
+                    last_key = key;
+                    have = true;
+                }
+                p.cls = (uint8_t)(last_v >> 8);
+                p.G = (uint8_t)(last_v & 0xff);
+                if (p.cls >= ct.n) {
+                    int64_t none = -1;
+                    unfit.compare_exchange_strong(none, gi);
+                }
+            }
+        });
+        if (unfit.load() >= 0) {
+            const Plan &p = gen[(size_t)unfit.load()];
+            agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", p.read, p.hap, p.H);
+            return AGX_E_LIMIT;
+        }
+    }
+    // dominant (R, H) shape?
+    if (n >= 1024 && n_cu > 0) {
+        const size_t stride = (size_t)n / 512;
+        uint32_t cand = 0;
+        int votes = 0;
+        for (size_t k = 0; k < 512; ++k) {
+            const uint32_t key = key_of(gen[k * stride]);
+            if (votes == 0) {
+                cand = key;
+                votes = 1;
+            } else
+                votes += key == cand ? 1 : -1;
+        }
+        std::atomic<int64_t> count{0};
+        if (one_shape)
+            count = n;
+        else
+            agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int) {
+                int64_t c = 0;
+                for (int64_t k = lo; k < hi; ++k) c += key_of(gen[(size_t)k]) == cand;
+                count.fetch_add(c, std::memory_order_relaxed);
+            });
+        if (votes > 0 && count.load() * 2 >= n) {
+            uint8_t c = 255, G = 0;
+            choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count.load() + slots - 1) / slots, 4 * n_cu, &c, &G);
+            if (c < ct.n)
+                agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int) {
+                    for (int64_t k = lo; k < hi; ++k)
+                        if (key_of(gen[(size_t)k]) == cand) {
+                            gen[(size_t)k].cls = c;
+                            gen[(size_t)k].G = G;
+                        }
+                });
+        }
+    }
+    tm3 = now_ms();
+    // order: class, lanes per group (wide first), then long reads first, read, haplotype -- a wave's
+    // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
+    // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
+    std::vector<Plan> plan;
+    if (one_shape)
+        plan.swap(gen); // one (R, H) shape: one class, one G, equal keys throughout
+    else {
+        const uint32_t max_r = all.r_max;
+        std::vector<Plan> tmp;
+        counting_sort(gen, tmp, (size_t)max_r + 1, [&](const Plan &p) { return (size_t)(max_r - p.R); });
+        counting_sort(tmp, plan, (size_t)ct.n * 64 + 1, [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); });
+    }
+    std::vector<Plan>().swap(gen);
+    tm4 = now_ms();
+    // Waves and records.  The greedy filling below runs on pieces of `plan` that start where the read, the class or
+    // the group width changes (a wave never spans such a piece's end; a packed group's partner is the next haplotype of
+    // the SAME read, so no group does either); the pieces' records are then laid end to end.
+    auto fill_waves = [&](size_t i, const size_t end, PlanOut &o) {
+        while (i < end) {
+            const int cls = plan[i].cls;
+            ClassLaunch cl;
+            cl.C = ct.C[cls];
+            cl.first_wave = (uint32_t)o.waves.size();
+            while (i < end && plan[i].cls == cls) {
+                const int G = plan[i].G;
+                const int per_wave = 64 / G;
+                PhWave w{};
+                w.first_group = (uint32_t)(slots == 2 ? o.groups2.size() : o.groups1.size());
+                w.first_tab = (uint32_t)o.tabs.size();
+                w.G = (uint16_t)G;
+                int cnt = 0;
+                uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
+                while (i < end && plan[i].cls == cls && plan[i].G == G && cnt < per_wave) {
+                    const Plan &p = plan[i];
+                    const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
+                    const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
+                    if (cnt > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget()) break;
+                    if (p.read != last_read) {
+                        o.tabs.push_back(PhTab{read_dw[p.read], p.R});
+                        last_read = p.read;
+                    }
+                    ntabs = ntabs_new;
+                    steps = nsteps;
+                    if (slots == 2) {
+                        PhGroup2 g{};
+                        g.R_tab = p.R | ((ntabs - 1) << 16);
+                        g.hap_dw[0] = hap_dw[p.hap];
+                        g.H[0] = p.H;
+                        g.out[0] = p.out;
+                        g.init32[0] = FLT_MAX / 16 / (float)p.H;
+                        // second slot: the next haplotype of the same read in this class, else vacant
+                        g.hap_dw[1] = 0;
+                        g.H[1] = 0;
+                        g.out[1] = vacant_out;
+                        g.init32[1] = 0;
+                        if (i + 1 < end && plan[i + 1].cls == cls && plan[i + 1].G == G && plan[i + 1].read == p.read) {
+                            const Plan &q = plan[i + 1];
+                            g.hap_dw[1] = hap_dw[q.hap];
+                            g.H[1] = q.H;
+                            g.out[1] = q.out;
+                            g.init32[1] = FLT_MAX / 16 / (float)q.H;
+                            ++i;
+                        }
+                        o.groups2.push_back(g);
+                    } else {
+                        PhGroup g{};
+                        g.hap_dw = hap_dw[p.hap];
+                        g.H = p.H;
+                        g.R_tab = p.R | ((ntabs - 1) << 16);
+                        g.out = p.out;
+                        g.init64 = DBL_MAX / 16 / (double)p.H;
+                        g.init32 = FLT_MAX / 16 / (float)p.H;
+                        o.groups1.push_back(g);
+                    }
+                    ++cnt;
+                    ++i;
+                }
+                w.n_groups = (uint16_t)cnt;
+                w.n_tabs = (uint16_t)ntabs;
+                w.steps = steps;
+                if (G != 16) cl.all_g16 = false;
+                cl.lds = std::max(cl.lds, tab_bytes(rows_f64, steps + G - 1) * ntabs);
+                cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
+                o.padded += (int64_t)steps * 64 * cl.C * slots;
+                o.waves.push_back(w);
+            }
+            cl.n_waves = (uint32_t)o.waves.size() - cl.first_wave;
+            o.launches.push_back(cl);
+        }
+    };
+    const std::vector<size_t> cut = cut_at_runs(plan.size(), run_parts, [&](size_t i) {
+        return plan[i].read != plan[i - 1].read || plan[i].cls != plan[i - 1].cls || plan[i].G != plan[i - 1].G;
+    });
+    const int pieces = (int)cut.size() - 1;
+    if (pieces <= 1)
+        fill_waves(0, plan.size(), po);
+    else {
+        std::vector<PlanOut> part((size_t)pieces);
+        agx_pool_run(pieces, [&](int t) {
+            PlanOut &o = part[(size_t)t];
+            const size_t span = cut[(size_t)t + 1] - cut[(size_t)t];
+            (slots == 2 ? o.groups2.reserve(span / 2 + 64) : o.groups1.reserve(span));
+            o.waves.reserve(span / 4 + 16);
+            o.tabs.reserve(span / 8 + 16);
+            fill_waves(cut[(size_t)t], cut[(size_t)t + 1], o);
+        });
+        size_t n_groups = 0, n_tabs = 0, n_waves = 0;
+        for (const PlanOut &o : part) n_groups += o.groups1.size() + o.groups2.size(), n_tabs += o.tabs.size(), n_waves += o.waves.size();
+        (slots == 2 ? po.groups2.resize(n_groups) : po.groups1.resize(n_groups));
+        po.tabs.resize(n_tabs);
+        po.waves.resize(n_waves);
+        std::vector<size_t> g0((size_t)pieces), t0((size_t)pieces), w0((size_t)pieces);
+        size_t ga = 0, ta = 0, wa = 0;
+        for (int t = 0; t < pieces; ++t) {
+            const PlanOut &o = part[(size_t)t];
+            g0[(size_t)t] = ga, t0[(size_t)t] = ta, w0[(size_t)t] = wa;
+            ga += o.groups1.size() + o.groups2.size(), ta += o.tabs.size(), wa += o.waves.size();
+            po.padded += o.padded;
+            for (ClassLaunch cl : o.launches) { // a class that runs on into the next piece is one launch
+                cl.first_wave += (uint32_t)w0[(size_t)t];
+                if (!po.launches.empty() && po.launches.back().C == cl.C) {
+                    ClassLaunch &m = po.launches.back();
+                    m.n_waves += cl.n_waves;
+                    m.all_g16 = m.all_g16 && cl.all_g16;
+                    m.lds = std::max(m.lds, cl.lds);
+                    m.lds_rescue = std::max(m.lds_rescue, cl.lds_rescue);
+                } else
+                    po.launches.push_back(cl);
+            }
+        }
+        agx_pool_run(pieces, [&](int t) {
+            const PlanOut &o = part[(size_t)t];
+            if (slots == 2)
+                std::copy(o.groups2.begin(), o.groups2.end(), po.groups2.begin() + (ptrdiff_t)g0[(size_t)t]);
+            else
+                std::copy(o.groups1.begin(), o.groups1.end(), po.groups1.begin() + (ptrdiff_t)g0[(size_t)t]);
+            std::copy(o.tabs.begin(), o.tabs.end(), po.tabs.begin() + (ptrdiff_t)t0[(size_t)t]);
+            for (size_t k = 0; k < o.waves.size(); ++k) {
+                PhWave w = o.waves[k];
+                w.first_group += (uint32_t)g0[(size_t)t];
+                w.first_tab += (uint32_t)t0[(size_t)t];
+                po.waves[w0[(size_t)t] + k] = w;
+            }
+        });
+    }
+    for (const ClassLaunch &cl : po.launches) {
+        // dispatch order = longest waves first (a wave lasts steps x C): the buckets were filled widest
+        // group first, which leaves narrow groups with long reads for the end of the launch
+        if (!one_shape)
+            std::stable_sort(po.waves.begin() + cl.first_wave, po.waves.begin() + cl.first_wave + cl.n_waves,
+                             [](const PhWave &a, const PhWave &b) { return a.steps > b.steps; });
+        if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
+            agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
+            return AGX_E_LIMIT;
+        }
+    }
+    if (trace)
+        fprintf(stderr, "[phmm make_plan kind %d] pairing+shapes %.2f, tiling %.2f, assign %.2f, sort %.2f, waves+records %.2f ms (%d pieces)\n",
+                kind, tm1 - tm0, tm2 - tm1, tm3 - tm2, tm4 - tm3, now_ms() - tm4, pieces);
+    return AGX_OK;
+}
+
 } // namespace
 
 struct agx_phmm_batch {
@@ -195,7 +631,8 @@ struct agx_phmm_batch {
     bool rescue_pending = false;  // packed batches: the rescue plan has not run for the last launch (it runs from
                                   // agx_phmm_batch_results, and only when the fill counted a pair below the float range)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
-    bool separate_rescue = false; // the double rescue pass has its own plan (packed batches)
+    bool separate_rescue = false; // the double rescue pass has its own plan (packed batches), made on first use from:
+    std::unique_ptr<PlanSeed> rescue_seed;
     DevBuf img, sums, lut, counter;
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
     struct DevPlan {
@@ -241,10 +678,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }
 
     const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto now = [] { return now_ms(); };
     const double t_begin = now();
     // ---- enumerate the pairs in output order: region, read, haplotype (threads over regions)
-    std::vector<Plan> gen0;
+    std::unique_ptr<PlanSeed> seed_holder(new PlanSeed());
+    PlanSeed &seed = *seed_holder;
+    seed.n_cu = n_cu;
+    seed.gatk_prior = gatk_prior;
+    std::vector<Plan> &gen0 = seed.gen0;
     int64_t n_pairs = 0, cells = 0;
     {
         const uint32_t ng = d->n_regions;
@@ -285,6 +726,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             }
         }
         n_pairs = out0[ng];
+        seed.n_pairs = n_pairs;
         gen0.resize((size_t)fill0[ng]);
         // (grain: about 16384 pairs per part -- smaller parts cost more in hand-over than they save)
         const int64_t region_grain = std::max<int64_t>(1, 16384 / std::max<int64_t>(1, n_pairs / std::max<uint32_t>(ng, 1)));
@@ -318,14 +760,18 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         uint32_t span = 0;
         for (int ci = 0; ci < ct.n; ++ci)
             if (ct.cost[ci] != 0) span = std::max(span, 64u * (uint32_t)ct.C[ci]);
-        size_t keep = 0;
-        for (const Plan &p : gen0) {
-            if (p.H > span)
-                gen_long.push_back(p);
-            else
-                gen0[keep++] = p;
+        uint64_t longest = 0;
+        for (uint32_t h = 0; d->hap_off && h < d->n_haps; ++h) longest = std::max<uint64_t>(longest, d->hap_off[h + 1] - d->hap_off[h]);
+        if (longest > span) {
+            size_t keep = 0;
+            for (const Plan &p : gen0) {
+                if (p.H > span)
+                    gen_long.push_back(p);
+                else
+                    gen0[keep++] = p;
+            }
+            gen0.resize(keep);
         }
-        gen0.resize(keep);
     }
 
     // ---- image: every read and haplotype once, shared by all plans of the batch.  Offsets come from two
@@ -333,7 +779,9 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // with a device the image is built straight in pinned staging memory.
     const size_t zero_dw = (64 * 32 + 8) / 4; // words 0..: an all-zero haplotype block for vacant packed slots (64 lanes x 32 columns)
     const uint32_t n_reads = d->read_off ? d->n_reads : 0, n_haps = d->hap_off ? d->n_haps : 0;
-    std::vector<uint32_t> read_dw(n_reads, 0xffffffffu), hap_dw(n_haps, 0xffffffffu);
+    std::vector<uint32_t> &read_dw = seed.read_dw, &hap_dw = seed.hap_dw;
+    read_dw.assign(n_reads, 0xffffffffu);
+    hap_dw.assign(n_haps, 0xffffffffu);
     size_t img_dw = zero_dw;
     const size_t stripe_bytes = 64u * (size_t)stripe_cols();
     auto hap_block_dw = [&](size_t H) { // zero slack: any class tiling, and whole stripes of the striped kernel, read in bounds
@@ -427,256 +875,17 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             }
         });
     }
-    auto put_read = [&](uint32_t) {};
-    auto put_hap = [&](uint32_t) {};
-
-    // ---- a plan: lane tilings, waves and records for one kernel family.
-    // kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group.
-    struct PlanOut {
-        std::vector<PhGroup> groups1;
-        std::vector<PhGroup2> groups2;
-        std::vector<PhTab> tabs;
-        std::vector<PhWave> waves;
-        std::vector<ClassLaunch> launches;
-        int64_t padded = 0;
-    };
-    auto make_plan = [&](int kind, int slots, bool rows_f64, PlanOut &po) -> int {
-        const double tm0 = now();
-        double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
-        const ClassTable ct = class_table(kind);
-        auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
-        std::vector<Plan> gen = gen0;
-        // Two haplotypes share a lane group in the packed kernel: within every read's run, order the
-        // haplotypes by length and tile neighbours for the longer of the two, so that partners get the
-        // same class (mixed-length regions would otherwise leave most second slots vacant).
-        for (Plan &p : gen) p.th = p.H;
-        // (fixed-length input -- BASELINE configs 3 and 5 -- needs neither this pairing nor the sorts below: every
-        // key is equal, the enumeration order already is the order they would produce)
-        bool one_shape = !gen.empty();
-        for (size_t k = 1; k < gen.size() && one_shape; ++k) one_shape = gen[k].R == gen[0].R && gen[k].H == gen[0].H;
-        if (slots == 2 && !one_shape) {
-            size_t a = 0;
-            while (a < gen.size()) {
-                size_t z = a;
-                while (z < gen.size() && gen[z].read == gen[a].read) ++z;
-                std::stable_sort(gen.begin() + (ptrdiff_t)a, gen.begin() + (ptrdiff_t)z,
-                                 [](const Plan &x, const Plan &y) { return x.H > y.H; });
-                for (size_t k = a; k < z; ++k) gen[k].th = gen[a + ((k - a) & ~(size_t)1)].H; // the pair's longer one
-                a = z;
-            }
-        }
-        // Tiling per (R, H) shape.  The per-class cost curve is flat over many widths, and every class
-        // is its own launch: a mixed batch first chooses freely, then keeps the few classes that carry
-        // most of the work and re-tiles the rest among them (a shape no kept class can span keeps its own).
-        std::unordered_map<uint32_t, uint32_t> shapes; // (R << 16 | H) -> count
-        for (const Plan &p : gen) ++shapes[p.R << 16 | p.th];
-        const uint64_t all_classes = ~0ull;
-        std::unordered_map<uint32_t, uint16_t> memo; // (R << 16 | H) -> cls << 8 | G
-        std::vector<double> class_work((size_t)ct.n, 0.0);
-        double waves_est = 0;
-        auto tile_all = [&](double beta) {
-            memo.clear();
-            std::fill(class_work.begin(), class_work.end(), 0.0);
-            waves_est = 0;
-            for (const auto &sh : shapes) {
-                uint8_t c = 255, G = 0;
-                double cost = 0;
-                choose_tiling(kind, sh.first >> 16, sh.first & 0xffffu, all_classes, &c, &G, &cost, beta);
-                memo.emplace(sh.first, (uint16_t)(c << 8 | G));
-                if (c < ct.n) {
-                    class_work[c] += cost * sh.second;
-                    waves_est += (double)sh.second * G / 64.0 / slots;
-                }
-            }
-        };
-        double beta = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
-        tm1 = now();
-        tile_all(beta);
-        // Tail regime (as in the SW planner): a batch whose waves fill the chip's resident capacity (3 waves
-        // per SIMD for the packed kernel, 2 for the others) less than 1.6 times lasts as long as its longest
-        // waves; it is re-tiled with 2 lanes' worth of extra cost on a wave's own duration, which spreads
-        // pairs over more lanes.  Mixed regions (tools/phmm_tail_beta_sweep.py): 2048 pairs +27 % packed /
-        // +35 % double, 16 384 pairs +30 % / +3 %; beyond 1.6 fillings the term costs a few percent.
-        if (tail_beta_override() < 0 && n_cu > 0 && waves_est / ((slots == 2 ? 3.0 : 2.0) * 4.0 * n_cu) < 1.6) {
-            beta = 2.0;
-            tile_all(beta);
-        }
-        {
-            // small batches afford fewer launches: about one class per 16384 wavefronts of work
-            // (tools/phmm_classes_sweep.py: the count matters little, fewer is never worse by more than 3 %)
-            const int k_max = std::min(max_classes(), 1 + (int)(waves_est / 16384.0));
-            int used = 0;
-            for (double wk : class_work) used += wk > 0;
-            if (used > k_max) {
-                std::vector<int> order((size_t)ct.n);
-                for (int k = 0; k < ct.n; ++k) order[(size_t)k] = k;
-                std::sort(order.begin(), order.end(), [&](int x, int y) { return class_work[(size_t)x] > class_work[(size_t)y]; });
-                uint64_t keep = 0;
-                for (int k = 0; k < k_max; ++k) keep |= 1ull << order[(size_t)k];
-                for (auto &m : memo) {
-                    if ((keep >> (m.second >> 8)) & 1u) continue;
-                    uint8_t c = 255, G = 0;
-                    choose_tiling(kind, m.first >> 16, m.first & 0xffffu, keep, &c, &G, nullptr, beta);
-                    if (c < ct.n) m.second = (uint16_t)(c << 8 | G);
-                }
-            }
-        }
-        tm2 = now();
-        for (size_t gi = 0; gi < gen.size(); ++gi) {
-            Plan &p = gen[gi];
-            const uint16_t v = memo[p.R << 16 | p.th];
-            p.cls = (uint8_t)(v >> 8);
-            p.G = (uint8_t)(v & 0xff);
-            if (p.cls >= ct.n) {
-                agx_set_error("pair (read %u, hap %u): no lane tiling fits %u columns", p.read, p.hap, p.H);
-                return AGX_E_LIMIT;
-            }
-        }
-        // dominant (R, H) shape?
-        if (gen.size() >= 1024 && n_cu > 0) {
-            const size_t stride = gen.size() / 512;
-            uint32_t cand = 0;
-            int votes = 0;
-            for (size_t k = 0; k < 512; ++k) {
-                const uint32_t key = gen[k * stride].R << 16 | gen[k * stride].th;
-                if (votes == 0) {
-                    cand = key;
-                    votes = 1;
-                } else
-                    votes += key == cand ? 1 : -1;
-            }
-            int64_t count = 0;
-            for (size_t k = 0; k < gen.size(); ++k)
-                if ((gen[k].R << 16 | gen[k].th) == cand) ++count;
-            if (votes > 0 && count * 2 >= (int64_t)gen.size()) {
-                uint8_t c = 255, G = 0;
-                choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count + slots - 1) / slots, 4 * n_cu, &c, &G);
-                if (c < ct.n)
-                    for (size_t k = 0; k < gen.size(); ++k)
-                        if ((gen[k].R << 16 | gen[k].th) == cand) {
-                            gen[k].cls = c;
-                            gen[k].G = G;
-                        }
-            }
-        }
-        tm3 = now();
-        // order: class, lanes per group (wide first), then long reads first, read, haplotype -- a wave's
-        // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
-        // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
-        std::vector<Plan> plan;
-        if (one_shape)
-            plan.swap(gen); // one (R, H) shape: one class, one G, equal keys throughout
-        else {
-            uint32_t max_r = 0;
-            for (const Plan &p : gen) max_r = std::max(max_r, p.R);
-            std::vector<Plan> tmp;
-            counting_sort(gen, tmp, (size_t)max_r + 1, [&](const Plan &p) { return (size_t)(max_r - p.R); });
-            counting_sort(tmp, plan, (size_t)ct.n * 64 + 1, [](const Plan &p) { return (size_t)p.cls * 64 + (size_t)(64 - p.G); });
-        }
-        std::vector<Plan>().swap(gen);
-        tm4 = now();
-        size_t i = 0;
-        while (i < plan.size()) {
-            const int cls = plan[i].cls;
-            ClassLaunch cl;
-            cl.C = ct.C[cls];
-            cl.first_wave = (uint32_t)po.waves.size();
-            while (i < plan.size() && plan[i].cls == cls) {
-                const int G = plan[i].G;
-                const int per_wave = 64 / G;
-                PhWave w{};
-                w.first_group = (uint32_t)(slots == 2 ? po.groups2.size() : po.groups1.size());
-                w.first_tab = (uint32_t)po.tabs.size();
-                w.G = (uint16_t)G;
-                int n = 0;
-                uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
-                while (i < plan.size() && plan[i].cls == cls && plan[i].G == G && n < per_wave) {
-                    const Plan &p = plan[i];
-                    const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
-                    const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                    if (n > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget()) break;
-                    if (p.read != last_read) {
-                        put_read(p.read);
-                        po.tabs.push_back(PhTab{read_dw[p.read], p.R});
-                        last_read = p.read;
-                    }
-                    ntabs = ntabs_new;
-                    steps = nsteps;
-                    put_hap(p.hap);
-                    if (slots == 2) {
-                        PhGroup2 g{};
-                        g.R_tab = p.R | ((ntabs - 1) << 16);
-                        g.hap_dw[0] = hap_dw[p.hap];
-                        g.H[0] = p.H;
-                        g.out[0] = p.out;
-                        g.init32[0] = FLT_MAX / 16 / (float)p.H;
-                        // second slot: the next haplotype of the same read in this class, else vacant
-                        g.hap_dw[1] = 0;
-                        g.H[1] = 0;
-                        g.out[1] = (uint32_t)n_pairs;
-                        g.init32[1] = 0;
-                        if (i + 1 < plan.size() && plan[i + 1].cls == cls && plan[i + 1].G == G && plan[i + 1].read == p.read) {
-                            const Plan &q = plan[i + 1];
-                            put_hap(q.hap);
-                            g.hap_dw[1] = hap_dw[q.hap];
-                            g.H[1] = q.H;
-                            g.out[1] = q.out;
-                            g.init32[1] = FLT_MAX / 16 / (float)q.H;
-                            ++i;
-                        }
-                        po.groups2.push_back(g);
-                    } else {
-                        PhGroup g{};
-                        g.hap_dw = hap_dw[p.hap];
-                        g.H = p.H;
-                        g.R_tab = p.R | ((ntabs - 1) << 16);
-                        g.out = p.out;
-                        g.init64 = DBL_MAX / 16 / (double)p.H;
-                        g.init32 = FLT_MAX / 16 / (float)p.H;
-                        po.groups1.push_back(g);
-                    }
-                    ++n;
-                    ++i;
-                }
-                w.n_groups = (uint16_t)n;
-                w.n_tabs = (uint16_t)ntabs;
-                w.steps = steps;
-                if (G != 16) cl.all_g16 = false;
-                cl.lds = std::max(cl.lds, tab_bytes(rows_f64, steps + G - 1) * ntabs);
-                cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
-                po.padded += (int64_t)steps * 64 * cl.C * slots;
-                po.waves.push_back(w);
-            }
-            cl.n_waves = (uint32_t)po.waves.size() - cl.first_wave;
-            // dispatch order = longest waves first (a wave lasts steps x C): the buckets were filled widest
-            // group first, which leaves narrow groups with long reads for the end of the launch
-            std::stable_sort(po.waves.begin() + cl.first_wave, po.waves.end(),
-                             [](const PhWave &a, const PhWave &b) { return a.steps > b.steps; });
-            if (std::max(cl.lds, cl.lds_rescue) > 160 * 1024) {
-                agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", cl.lds);
-                return AGX_E_LIMIT;
-            }
-            po.launches.push_back(cl);
-        }
-        if (trace)
-            fprintf(stderr, "[phmm make_plan kind %d] copy+pairing %.2f, tiling %.2f, assign %.2f, sort %.2f, waves+image %.2f ms\n", kind,
-                    tm1 - tm0, tm2 - tm1, tm3 - tm2, tm4 - tm3, now() - tm4);
-        return AGX_OK;
-    };
-
     if (trace) fprintf(stderr, "[phmm create] enumerate %.2f ms\n", now() - t_begin);
-    PlanOut pmain, presc;
-    rc = make_plan(precision, packed ? 2 : 1, f64, pmain);
-    // a packed float batch cannot reuse its records for the double rescue pass: second plan
-    if (!rc && packed) rc = make_plan(AGX_PHMM_F64, 1, true, presc);
+    // A packed float batch cannot reuse its records for the double rescue pass: that pass has a plan of its own, made
+    // from the kept seed when a fill first counts a pair below the float range (ensure_rescue_plan).
+    PlanOut pmain;
+    rc = packed ? make_plan(seed, gen0, 3, 2, false, trace, pmain) : make_plan(seed, std::move(gen0), precision, 1, f64, trace, pmain);
     if (rc) return rc;
     // striped plan: one pair per wavefront, every pair its own read table
     PlanOut pstripe;
     uint32_t stripe_steps = 0;
     size_t stripe_lds = 0;
     for (const Plan &p : gen_long) {
-        put_read(p.read);
-        put_hap(p.hap);
         PhWave w{};
         w.first_group = (uint32_t)pstripe.groups1.size();
         w.first_tab = (uint32_t)pstripe.tabs.size();
@@ -733,7 +942,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->separate_rescue = packed;
     b->n_pairs = n_pairs;
     b->main.launches = pmain.launches;
-    b->rescue.launches = presc.launches;
+    if (packed) b->rescue_seed = std::move(seed_holder); // (`seed` stays valid: the batch owns it now)
     const size_t groups_bytes = packed ? pmain.groups2.size() * sizeof(PhGroup2) : pmain.groups1.size() * sizeof(PhGroup);
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
@@ -741,7 +950,8 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->info.input_bytes = (int64_t)(img_dw * 4 + groups_bytes + pmain.tabs.size() * sizeof(PhTab) +
                                     pmain.waves.size() * sizeof(PhWave));
     const bool two_pass = precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA;
-    b->info.n_launches = (int32_t)(pmain.launches.size() + (packed ? presc.launches.size() : two_pass ? pmain.launches.size() : 0));
+    // (a packed batch's rescue plan is not counted: it is launched only when a fill underflowed)
+    b->info.n_launches = (int32_t)(pmain.launches.size() + (!packed && two_pass ? pmain.launches.size() : 0));
     b->info.n_waves = (int32_t)(pmain.waves.size() + pstripe.waves.size());
     if (!pstripe.waves.empty()) {
         ClassLaunch cl;
@@ -777,11 +987,6 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     pieces.push_back(Piece{&b->main.groups, packed ? (const void *)pmain.groups2.data() : (const void *)pmain.groups1.data(), groups_bytes});
     pieces.push_back(Piece{&b->main.tabs, pmain.tabs.data(), pmain.tabs.size() * sizeof(PhTab)});
     pieces.push_back(Piece{&b->main.waves, pmain.waves.data(), pmain.waves.size() * sizeof(PhWave)});
-    if (packed) {
-        pieces.push_back(Piece{&b->rescue.groups, presc.groups1.data(), presc.groups1.size() * sizeof(PhGroup)});
-        pieces.push_back(Piece{&b->rescue.tabs, presc.tabs.data(), presc.tabs.size() * sizeof(PhTab)});
-        pieces.push_back(Piece{&b->rescue.waves, presc.waves.data(), presc.waves.size() * sizeof(PhWave)});
-    }
     if (!pstripe.waves.empty()) {
         pieces.push_back(Piece{&b->stripe.groups, pstripe.groups1.data(), pstripe.groups1.size() * sizeof(PhGroup)});
         pieces.push_back(Piece{&b->stripe.tabs, pstripe.tabs.data(), pstripe.tabs.size() * sizeof(PhTab)});
@@ -951,6 +1156,43 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
 // float sums and recomputes those below the float range.  Run from agx_phmm_batch_results, when the fill counted any.
 static int launch_rescue_plan(agx_phmm_batch *b)
 {
+    if (b->rescue_seed) { // first underflow of this batch: plan the double pass over the same pairs and upload its records
+        PlanOut pr;
+        const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
+        int rc = make_plan(*b->rescue_seed, std::move(b->rescue_seed->gen0), AGX_PHMM_F64, 1, true, trace, pr);
+        b->rescue_seed.reset();
+        if (rc) return rc;
+        struct Piece {
+            DevBuf *dst;
+            const void *src;
+            size_t bytes;
+        } pieces[3] = {{&b->rescue.groups, pr.groups1.data(), pr.groups1.size() * sizeof(PhGroup)},
+                       {&b->rescue.tabs, pr.tabs.data(), pr.tabs.size() * sizeof(PhTab)},
+                       {&b->rescue.waves, pr.waves.data(), pr.waves.size() * sizeof(PhWave)}};
+        size_t stage_bytes = 0;
+        for (const Piece &pc : pieces) stage_bytes += (pc.bytes + 255) & ~(size_t)255;
+        PinBuf stage;
+        struct StageGuard {
+            PinBuf &s;
+            ~StageGuard() { s.release(); }
+        } stage_guard{stage};
+        rc = stage.alloc(b->ctx, stage_bytes);
+        for (const Piece &pc : pieces)
+            if (!rc) rc = pc.dst->alloc(b->ctx, pc.bytes);
+        if (!rc && pr.launches.size() > 1) rc = agx_ctx_prepare_fanout(b->ctx);
+        if (rc) return rc;
+        hipStream_t cs = b->ctx->copy;
+        size_t at = 0;
+        for (const Piece &pc : pieces) {
+            if (pc.bytes) {
+                memcpy((char *)stage.p + at, pc.src, pc.bytes);
+                AGX_HIP(hipMemcpyAsync(pc.dst->p, (char *)stage.p + at, pc.bytes, hipMemcpyHostToDevice, cs));
+            }
+            at += (pc.bytes + 255) & ~(size_t)255;
+        }
+        AGX_HIP(hipStreamSynchronize(cs));
+        b->rescue.launches = pr.launches;
+    }
     const void *lut_d = b->lut.p;
     const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
     FanOut fan(b->ctx, (int)b->rescue.launches.size());

@@ -169,6 +169,42 @@ def test_many_small_regions_and_table_sharing(ctx, oracle):
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA), l_ref) <= 1e-6  # odd haplotype counts: vacant packed halves
 
 
+def test_planner_paths_wide_window_and_threaded_pieces(ctx, oracle):
+    """The planner counts shapes in a dense table over the batch's window of lengths (<= 2^20 cells) or through a hash
+    map (wider windows), and fills waves on pieces of the ordered pair list that are laid end to end afterwards: both
+    paths, and a mixed batch large enough for several pieces, against the oracle in every precision."""
+    wide = []
+    for k, (n, h, R, H) in enumerate([(3, 2, 20, 30), (2, 3, 900, 1990), (4, 5, 150, 300), (1, 1, 4, 7), (2, 2, 640, 33)]):
+        wide += _as_regions(synth.phmm_regions(1, n, h, R, H, seed=700 + k, jitter=3))
+    big = synth.phmm_regions(40, 48, 14, 150, 380, seed=84, jitter=100)  # 26 880 pairs, nearly all shapes distinct
+    for b in (synth.phmm_from_regions(wide), big):
+        s_ref, l_ref = oracle_api.phmm_batch_mt(oracle, b, 0) if b is big else oracle.phmm_batch(b, 0)
+        for prec, tol in ((agx.PHMM_F64, 0.0), (agx.PHMM_F64_FMA, 1e-12), (agx.PHMM_F32, 1e-6), (agx.PHMM_F32_FMA, 1e-6)):
+            dev = ctx.phmm_batch(b, prec)
+            dev.launch()
+            l, s = dev.results()
+            dev.close()
+            if prec == agx.PHMM_F64:
+                assert np.array_equal(s, s_ref) and np.array_equal(l, l_ref)
+            else:
+                assert relerr(l, l_ref) <= tol
+
+
+def test_packed_rescue_plan_is_made_on_first_underflow_and_reused(ctx, oracle, golden_dir):
+    """A packed float batch plans and uploads its double rescue pass when a fill first counts a pair below the float
+    range (phmm_far: every pair), then reuses it: results of the first, second and third launch agree with the oracle."""
+    b, _, _ = agx.read_phmm_text(os.path.join(golden_dir, "phmm_far.in"))
+    _, l_ref = oracle.phmm_batch(b, 0)
+    dev = ctx.phmm_batch(b, agx.PHMM_F32_FMA)
+    got = []
+    for _ in range(3):
+        dev.launch()
+        got.append(dev.results()[0])
+    assert dev.info().n_rescued > 0
+    dev.close()
+    assert relerr(got[0], l_ref) <= 1e-6 and np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+
+
 def _as_regions(p):
     out = []
     for g in range(p.n_regions):
