@@ -222,9 +222,10 @@ std::vector<size_t> cut_at_runs(size_t n, int parts, F is_cut)
     return cut;
 }
 
-// kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group; `gen` (a copy of
-// seed.gen0, or seed.gen0 itself when nobody needs it afterwards) is consumed.
-int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, bool rows_f64, bool trace, PlanOut &po)
+// kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group; lut_rows: the read
+// tables have the rows of agx_phmm_lut_kernel.hip; `gen` (a copy of seed.gen0, or seed.gen0 itself when nobody needs
+// it afterwards) is consumed.
+int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, bool rows_f64, bool lut_rows, bool trace, PlanOut &po)
 {
     const double tm0 = now_ms();
     double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
@@ -233,7 +234,9 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     const int n_cu = seed.n_cu;
     const std::vector<uint32_t> &read_dw = seed.read_dw, &hap_dw = seed.hap_dw;
     const uint32_t vacant_out = (uint32_t)seed.n_pairs;
-    auto tab_bytes = [&](bool f64, uint32_t rows) { return slots == 2 ? ph_pk_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows); };
+    auto tab_bytes = [&](bool f64, uint32_t rows) {
+        return slots == 2 ? ph_pk_tab_bytes(rows) : lut_rows ? ph_lut_tab_bytes(rows) : ph_tab_bytes(f64, gatk_prior, rows);
+    };
     const int64_t n = (int64_t)gen.size();
     auto key_of = [](const Plan &p) { return p.R << 16 | p.th; };
     // Two haplotypes share a lane group in the packed kernel: within every read's run, order the
@@ -631,6 +634,7 @@ struct agx_phmm_batch {
     bool rescue_pending = false;  // packed batches: the rescue plan has not run for the last launch (it runs from
                                   // agx_phmm_batch_results, and only when the fill counted a pair below the float range)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
+    bool lut_prior = false;       // double modes on plain DNA: priors looked up in the read tables (agx_phmm_lut_kernel.hip)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches), made on first use from:
     std::unique_ptr<PlanSeed> rescue_seed;
     DevBuf img, sums, lut, counter;
@@ -827,7 +831,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // packed float fill: its fast cell (agx_phmm_pk_kernel.hip) divides by 1 - Qg and codes the bases in two bits, so a
     // gap-continuation quality of Phred 0 or below, a read base outside ACGTN or a haplotype base outside ACGT anywhere
     // in the batch keeps the plain cell
-    std::atomic<bool> not_fast{false};
+    std::atomic<bool> not_fast{false}, not_dna{false}; // not_dna: a read base outside ACGTN or a haplotype base outside ACGT
     static const auto dna_table = [] {
         std::array<uint8_t, 256> t{};
         for (const char *p = "ACGT"; *p; ++p) t[(uint8_t)*p] = 3; // bit 0: allowed in a read, bit 1: in a haplotype
@@ -836,11 +840,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }();
     if (have_tracks) {
         agx_parallel_for((int64_t)n_reads, 2048, [&](int64_t ra, int64_t rz, int) {
-            bool zero = false;
-            for (int64_t r = ra; r < rz && packed && !probs; ++r)
-                for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k)
-                    zero |= d->q_gcp[k] <= (uint8_t)'!' || !(dna_table[d->read_bases[k]] & 1);
-            if (zero) not_fast.store(true, std::memory_order_relaxed);
+            bool zero = false, other = false;
+            for (int64_t r = ra; r < rz && !probs && precision != AGX_PHMM_F32; ++r)
+                for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k) {
+                    zero |= packed && d->q_gcp[k] <= (uint8_t)'!';
+                    other |= !(dna_table[d->read_bases[k]] & 1);
+                }
+            if (zero || other) not_fast.store(true, std::memory_order_relaxed);
+            if (other) not_dna.store(true, std::memory_order_relaxed);
             for (int64_t r = ra; r < rz; ++r) {
                 const uint64_t o = d->read_off[r];
                 const size_t R = (size_t)(d->read_off[r + 1] - o), trk = (R + 3) / 4;
@@ -866,10 +873,13 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 const size_t H = (size_t)(d->hap_off[h + 1] - o);
                 uint8_t *p = reinterpret_cast<uint8_t *>(img + hap_dw[(size_t)h]);
                 memcpy(p, d->hap_bases + o, H);
-                if (packed) {
+                if (!probs && precision != AGX_PHMM_F32) {
                     bool other = false;
                     for (size_t k = 0; k < H; ++k) other |= !(dna_table[d->hap_bases[o + k]] & 2);
-                    if (other) not_fast.store(true, std::memory_order_relaxed);
+                    if (other) {
+                        not_fast.store(true, std::memory_order_relaxed);
+                        not_dna.store(true, std::memory_order_relaxed);
+                    }
                 }
                 memset(p + H, 0, hap_block_dw(H) * 4 - H);
             }
@@ -878,8 +888,11 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (trace) fprintf(stderr, "[phmm create] enumerate %.2f ms\n", now() - t_begin);
     // A packed float batch cannot reuse its records for the double rescue pass: that pass has a plan of its own, made
     // from the kept seed when a fill first counts a pair below the float range (ensure_rescue_plan).
+    // double modes on plain DNA run the kernel whose read tables carry the priors (other rows, other LDS sizes)
+    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && !agx_tune("AGX_PHMM_NO_LUT");
     PlanOut pmain;
-    rc = packed ? make_plan(seed, gen0, 3, 2, false, trace, pmain) : make_plan(seed, std::move(gen0), precision, 1, f64, trace, pmain);
+    rc = packed ? make_plan(seed, gen0, 3, 2, false, false, trace, pmain)
+                : make_plan(seed, std::move(gen0), precision, 1, f64, lut_prior, trace, pmain);
     if (rc) return rc;
     // striped plan: one pair per wavefront, every pair its own read table
     PlanOut pstripe;
@@ -932,10 +945,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->gatk_prior = gatk_prior;
     b->packed = packed;
     b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
+    b->lut_prior = lut_prior;
     // the code objects this batch will launch from, loaded now rather than inside its first launch
     if (ctx) {
         if (packed) agx_phmm_pk_preload();
         agx_phmm_scalar_preload();
+        if (lut_prior) agx_phmm_lut_preload();
         agx_copy_preload();
         if (precision == AGX_PHMM_F32 || precision == AGX_PHMM_F32_FMA) agx_phmm_finish_preload();
     }
@@ -1137,6 +1152,15 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
                     return AGX_E_HIP;
                 }
+            } else if (b->lut_prior) {
+                const int r = agx_phmm_lut_launch_class(b->precision == AGX_PHMM_F64_FMA, cl.C, cl.all_g16, (const uint32_t *)b->img.p,
+                                                        (const PhGroup *)b->main.groups.p, (const PhTab *)b->main.tabs.p,
+                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_d, mis_for_d,
+                                                        (double *)b->sums.p, cl.lds, st);
+                if (r) {
+                    agx_set_error("phmm_fill_lut<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
+                    return AGX_E_HIP;
+                }
             } else {
                 int mode = b->precision;
                 if (b->probs) mode = 4;
@@ -1159,7 +1183,7 @@ static int launch_rescue_plan(agx_phmm_batch *b)
     if (b->rescue_seed) { // first underflow of this batch: plan the double pass over the same pairs and upload its records
         PlanOut pr;
         const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
-        int rc = make_plan(*b->rescue_seed, std::move(b->rescue_seed->gen0), AGX_PHMM_F64, 1, true, trace, pr);
+        int rc = make_plan(*b->rescue_seed, std::move(b->rescue_seed->gen0), AGX_PHMM_F64, 1, true, false, trace, pr);
         b->rescue_seed.reset();
         if (rc) return rc;
         struct Piece {

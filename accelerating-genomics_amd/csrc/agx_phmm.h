@@ -80,6 +80,11 @@ __host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, ui
     return (ph_row_bytes(f64, mis_col) * rows + 15u) & ~(size_t)15u;
 }
 
+// the double kernel with looked-up priors (agx_phmm_lut_kernel.hip): one row of {Qi, Qd, Qg, prior[A], prior[C], prior[T], prior[G]}
+// per read position
+#define AGX_PH_LUT_ROW_BYTES 56u
+#define AGX_PH_LUT_W2_FROM 32 /* widths from here on are built for two waves per SIMD */
+__host__ __device__ static inline size_t ph_lut_tab_bytes(uint32_t rows) { return ((size_t)rows * AGX_PH_LUT_ROW_BYTES + 15u) & ~(size_t)15u; }
 // the packed float kernel's tables: one 32-byte row of derived values per read position
 __host__ __device__ static inline size_t ph_pk_tab_bytes(uint32_t rows) { return (size_t)rows * 32u; }
 
@@ -107,6 +112,11 @@ int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, con
                            uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 // float modes: log10(sum) - log10(C) per pair on the device (a negated sum = recomputed in double, scaled by DBL_MAX/16)
+// AGX_PHMM_F64 / F64_FMA on plain DNA (reads of ACGTN, haplotypes of ACGT): the prior comes from the read's LDS table
+int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups,
+                              const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis,
+                              double *sums, size_t lds_bytes, hipStream_t s);
+void agx_phmm_lut_preload();
 void agx_phmm_pk_preload();
 void agx_phmm_scalar_preload();
 void agx_phmm_finish_preload();

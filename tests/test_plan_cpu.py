@@ -114,7 +114,9 @@ def test_substitution_matrix_plans_and_validation():
     assert e.value.code == agx.E_LIMIT
 
 
-@pytest.mark.parametrize("prec,floor", [(agx.PHMM_F32_FMA, 0.70), (agx.PHMM_F64, 0.78)])
+# (F64 on plain DNA plans for the kernel with looked-up priors: 56-byte table rows instead of 33, so fewer read tables
+# fit a wave's 20 KB of LDS and mixed regions pad a little more -- 0.75 against 0.79 -- for 12 instead of 14 instructions per cell)
+@pytest.mark.parametrize("prec,floor", [(agx.PHMM_F32_FMA, 0.70), (agx.PHMM_F64, 0.74)])
 def test_mixed_shape_regions_plan_with_few_classes_and_little_padding(prec, floor):
     """Reads of 50..150 and haplotypes of 280..380 within every region: the planner pairs haplotypes of
     similar length (packed kernel), keeps the few classes that carry most of the work and fills waves
