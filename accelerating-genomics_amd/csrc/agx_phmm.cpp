@@ -492,13 +492,19 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                 w.G = (uint16_t)G;
                 int cnt = 0;
                 uint32_t steps = 0, ntabs = 0, last_read = 0xffffffffu;
+                size_t lut_bytes = 0; // lut_rows: every table is as long as its own read (+ a neutral row at either end)
                 while (i < end && plan[i].cls == cls && plan[i].G == G && cnt < per_wave) {
                     const Plan &p = plan[i];
                     const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
                     const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
-                    if (cnt > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget()) break;
+                    if (lut_rows) {
+                        if (cnt > 0 && p.read != last_read && lut_bytes + ph_lut_tab_bytes(p.R + 2u) > tab_budget()) break;
+                    } else if (cnt > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget())
+                        break;
                     if (p.read != last_read) {
-                        o.tabs.push_back(PhTab{read_dw[p.read], p.R});
+                        // (lut_rows: the table's offset / 16 rides in the upper half of R, agx_phmm_lut_kernel.hip)
+                        o.tabs.push_back(PhTab{read_dw[p.read], lut_rows ? p.R | (uint32_t)(lut_bytes / 16) << 16 : p.R});
+                        if (lut_rows) lut_bytes += ph_lut_tab_bytes(p.R + 2u);
                         last_read = p.read;
                     }
                     ntabs = ntabs_new;
@@ -541,7 +547,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                 w.n_tabs = (uint16_t)ntabs;
                 w.steps = steps;
                 if (G != 16) cl.all_g16 = false;
-                cl.lds = std::max(cl.lds, tab_bytes(rows_f64, steps + G - 1) * ntabs);
+                cl.lds = std::max(cl.lds, lut_rows ? lut_bytes : tab_bytes(rows_f64, steps + G - 1) * ntabs);
                 cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
                 o.padded += (int64_t)steps * 64 * cl.C * slots;
                 o.waves.push_back(w);

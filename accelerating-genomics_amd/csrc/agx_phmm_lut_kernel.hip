@@ -9,6 +9,9 @@
 //
 //     row r of a table = { Qi, Qd, Qg, prior[A], prior[C], prior[T], prior[G] }        (7 doubles = 56 bytes)
 //     prior[c] = (read base == c or read base == 'N') ? 1 - Qr : Qr  (Qr/3 with AGX_PHMM_GATK_PRIOR)
+//     a table = one neutral row, the read's R rows, one neutral row: a lane clamps its row index (v_med3_i32) instead
+//     of walking G-1 stored neutral rows at either end, and every table is as long as ITS read (PhTab.R carries the
+//     table's offset / 16 in its upper half) -- mixed regions fit more tables into a wave's 20 KB
 //
 // and a cell fetches its prior with ONE VALU instruction (v_add_u32_sdwa: row offset + the column's letter code * 8,
 // the codes sit pre-scaled in the bytes of the lane's haplotype registers) and one ds_read_b64, which issues on the
@@ -35,6 +38,26 @@ __device__ __forceinline__ double rshr1(double v)
 }
 
 constexpr uint32_t kRow = AGX_PH_LUT_ROW_BYTES; // 56
+
+// LDS by byte offset: the written-out add below hands over plain numbers, and `lds + number` would cost an instruction
+// per use (the array's own offset is a link-time constant the compiler cannot fold through the assembly)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+__device__ __forceinline__ double lds_double(uint32_t off) { return *reinterpret_cast<lds_cdouble *>(off); }
+
+// base + byte `b` of packed, in one instruction.  Written out because the compiler, left alone, extracts the C bytes
+// into C registers of their own before the loop (24 VGPRs more at 32 columns per lane: spills inside the cell loop).
+__device__ __forceinline__ uint32_t add_byte(uint32_t base, uint32_t packed, int b)
+{
+    uint32_t r;
+    switch (b & 3) {
+    case 0: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(packed)); break;
+    case 1: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(packed)); break;
+    case 2: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(packed)); break;
+    default: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(packed)); break;
+    }
+    return r;
+}
 
 template <int C, bool FMA, bool ROW16>
 __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
@@ -63,15 +86,17 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
     const int H = (int)g.H;
 
     // ---- read tables -> LDS
-    const uint32_t rows = w.steps + (uint32_t)G - 1u;
-    const uint32_t tab_bytes = (uint32_t)ph_lut_tab_bytes(rows);
+    uint32_t my_tab = 0; // byte offset of this group's table
     for (uint32_t k = 0; k < w.n_tabs; ++k) {
-        const PhTab tb = tabs[w.first_tab + k];
-        double *tq = reinterpret_cast<double *>(lds + k * tab_bytes);
+        PhTab tb = tabs[w.first_tab + k];
+        const uint32_t tab_off = (tb.R >> 16) * 16u;
+        tb.R &= 0xffffu;
+        if (k == (g.R_tab >> 16)) my_tab = tab_off;
+        double *tq = reinterpret_cast<double *>(lds + tab_off);
         const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
         const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
-        for (uint32_t r = lane; r < rows; r += 64) {
-            const int i = (int)r - (G - 1);
+        for (uint32_t r = lane; r < tb.R + 2u; r += 64) {
+            const int i = (int)r - 1;
             double vi = 0, vd = 0, vg = 1, e0 = 0, e1 = 0, e2 = 0, e3 = 0; // neutral row
             if (i >= 0 && i < (int)tb.R) {
                 const uint32_t c = rp[i];
@@ -125,15 +150,16 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
     double acc_prev = 0, result = 0;  // the sum runs down the lanes in column order (reference order, :206-212)
     const int steps = (int)w.steps;
     const int col0 = gl * C;
-    // this lane's row of step 0: G-1-gl neutral rows in, so that lane gl sits on read row t - gl
-    uint32_t rowoff = (g.R_tab >> 16) * tab_bytes + (uint32_t)(G - 1 - gl) * kRow;
+    // lane gl sits on read row t - gl: table row clamp(t - gl, -1, R) + 1
+    int trow = 1 - gl;
 
-    for (int t = 0; t < steps; ++t, rowoff += kRow) {
-        const double q_i = *reinterpret_cast<const double *>(lds + rowoff);
-        const double q_d = *reinterpret_cast<const double *>(lds + rowoff + 8);
-        const double q_g = *reinterpret_cast<const double *>(lds + rowoff + 16);
+    my_tab += (uint32_t)reinterpret_cast<uintptr_t>((lds_byte *)lds); // from here on an LDS address
+    for (int t = 0; t < steps; ++t, ++trow) {
+        const uint32_t rowoff = my_tab + (uint32_t)min(max(trow, 0), R + 1) * kRow; // v_med3_i32
+        const double q_i = lds_double(rowoff), q_d = lds_double(rowoff + 8), q_g = lds_double(rowoff + 16);
         const double mm = 1 - (q_i + q_d); // mm() (:115-117)
         const double gm = 1 - q_g;
+        const uint32_t priors = rowoff + 24u; // (added here: behind the written-out add the compiler would not fold it into the read's offset)
 
         double lM, lX, lY, acc; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
         if constexpr (ROW16) {
@@ -161,8 +187,7 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
         // overwritten yet
 #pragma unroll
         for (int j = C - 1; j >= 0; --j) {
-            const uint32_t code8 = (cw[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            const double prior = *reinterpret_cast<const double *>(lds + (rowoff + code8) + 24);
+            const double prior = lds_double(add_byte(priors, cw[j >> 2], j));
             const double dM = j ? M[j > 0 ? j - 1 : 0] : dM0;
             const double dX = j ? X[j > 0 ? j - 1 : 0] : dX0;
             const double dY = j ? Y[j > 0 ? j - 1 : 0] : dY0;
