@@ -643,6 +643,7 @@ struct agx_phmm_batch {
     bool lut_prior = false;       // double modes on plain DNA: priors looked up in the read tables (agx_phmm_lut_kernel.hip)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches), made on first use from:
     std::unique_ptr<PlanSeed> rescue_seed;
+    bool rescue_broken = false; // making that plan failed (out of memory): the batch's float results cannot be completed
     DevBuf img, sums, lut, counter;
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
     struct DevPlan {
@@ -1186,11 +1187,20 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
 // float sums and recomputes those below the float range.  Run from agx_phmm_batch_results, when the fill counted any.
 static int launch_rescue_plan(agx_phmm_batch *b)
 {
+    if (b->rescue_broken) {
+        agx_set_error("agx_phmm_batch_results: the double rescue pass of this batch could not be planned earlier; create the batch again");
+        return AGX_E_NOMEM;
+    }
     if (b->rescue_seed) { // first underflow of this batch: plan the double pass over the same pairs and upload its records
+        struct Broken { // any way out of this block but its end leaves the batch without the plan it needs
+            agx_phmm_batch *b;
+            bool done = false;
+            ~Broken() { b->rescue_broken = !done; }
+        } broken{b};
         PlanOut pr;
         const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
-        int rc = make_plan(*b->rescue_seed, std::move(b->rescue_seed->gen0), AGX_PHMM_F64, 1, true, false, trace, pr);
-        b->rescue_seed.reset();
+        std::unique_ptr<PlanSeed> seed = std::move(b->rescue_seed);
+        int rc = make_plan(*seed, std::move(seed->gen0), AGX_PHMM_F64, 1, true, false, trace, pr);
         if (rc) return rc;
         struct Piece {
             DevBuf *dst;
@@ -1222,6 +1232,7 @@ static int launch_rescue_plan(agx_phmm_batch *b)
         }
         AGX_HIP(hipStreamSynchronize(cs));
         b->rescue.launches = pr.launches;
+        broken.done = true;
     }
     const void *lut_d = b->lut.p;
     const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));

@@ -446,6 +446,9 @@ def main():
                               unit="pairs/s", dtype="f64", gcups=n_gpus * c5.cells() * c5_t["steps"] / c5_t["dt"] / 1e9,
                               launches_per_step=c5_info.n_launches, useful_cell_fraction=c5_info.cells / max(1, c5_info.padded_cells),
                               log10_checksum=c5_sum, roofline=roof(c5.algorithmic_bytes(), c5_t["launch_ms"], None),
+                              valu={"ops_per_cell": "12 instructions per cell: the reference's 11 fp64 operations in its order (7 v_mul_f64, 4 v_add_f64) + "
+                                                    "v_add_u32_sdwa (the prior is read from the read's LDS table, ds_read_b64)",
+                                    "frac_of_instruction_mix_ceiling": c5_info.padded_cells * (12 / VALU_PACKED) / (c5_t["launch_ms"] * 1e-3)},
                               total=dict(strong(s5_t, s5_rows, c5f.n_pairs, "pairs/s", "cells"),
                                          workload="ONE batch of 262 144 pairs R=250 H=500 (512 regions) cut into %d shards of whole regions by cells (agx_phmm_shard_cuts)" % world),
                               per_rank=s5_rows,
