@@ -287,7 +287,8 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     // The shapes of a batch live in a window of read and haplotype lengths: they are counted in a dense table over
     // that window (threads add to it directly) when it has at most 2^20 cells, else through a hash map.
     const uint64_t win_r = n ? (uint64_t)all.r_max - all.r_min + 1 : 0, win_h = n ? (uint64_t)all.h_max - all.h_min + 1 : 0;
-    const bool dense = win_r * win_h <= ((uint64_t)1 << 20);
+    // (... and no more than eight cells per pair beyond 65 536: a small batch with a wide window goes through the map)
+    const bool dense = win_r * win_h <= std::min<uint64_t>((uint64_t)1 << 20, std::max<uint64_t>(65536, 8 * (uint64_t)n));
     std::unordered_map<uint32_t, uint32_t> sparse_slot; // key -> slot (batches whose window is too wide)
     auto slot_of = [&](uint32_t key) -> size_t {
         if (dense) return (size_t)((key >> 16) - all.r_min) * (size_t)win_h + ((key & 0xffffu) - all.h_min);
