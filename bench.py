@@ -234,8 +234,13 @@ def main():
                 fetch()  # waits for the stream, copies the results into host memory
                 per[k] = time.perf_counter() - ta
         kern = np.array(kern)
+        # every step ended with its results on the host (fetch() waits for the stream), so this rank's K steps are
+        # complete here: its clock stops, THEN the ranks meet and the slowest one's time is the job's
+        torch.cuda.synchronize()
+        ctx.sync()
+        mine = time.perf_counter() - t0
         barrier()
-        dt = agd.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+        dt = agd.max_over_ranks(mine, device=red_dev)
         ctx.timer_start()
         for _ in range(steps):
             dev.launch()
