@@ -897,7 +897,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // A packed float batch cannot reuse its records for the double rescue pass: that pass has a plan of its own, made
     // from the kept seed when a fill first counts a pair below the float range (ensure_rescue_plan).
     // double modes on plain DNA run the kernel whose read tables carry the priors (other rows, other LDS sizes)
-    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && !agx_tune("AGX_PHMM_NO_LUT");
+    // (... while the longest read's table stays below 40 KB -- 730 rows: beyond that the 33-byte rows of phmm_fill keep
+    // more waves on a CU, and a 4096-row read fits the 160 KB only there)
+    uint64_t longest_read = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) longest_read = std::max<uint64_t>(longest_read, d->read_off[r + 1] - d->read_off[r]);
+    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && ph_lut_tab_bytes((uint32_t)longest_read + 2u) <= 40u * 1024u &&
+                           !agx_tune("AGX_PHMM_NO_LUT");
     PlanOut pmain;
     rc = packed ? make_plan(seed, gen0, 3, 2, false, false, trace, pmain)
                 : make_plan(seed, std::move(gen0), precision, 1, f64, lut_prior, trace, pmain);

@@ -354,6 +354,22 @@ def test_largest_supported_shapes(ctx, oracle):
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA), l_ref) <= 1e-12
     b2 = synth.phmm_regions(1, 2, 3, 4096, 1900, seed=78)  # packed float kernel: 64 lanes x 30 columns
     assert relerr(ctx.phmm_forward(b2, agx.PHMM_F32_FMA), oracle.phmm_batch(b2, 0)[1]) <= 1e-6
+    # a read of the full 4096 rows against short haplotypes (R > H): too long for the looked-up-prior fill's tables, so
+    # the double modes take phmm_fill; a 700-row read beside it in another batch still runs the looked-up priors
+    rng = np.random.default_rng(79)
+    for R in (4096, 700):
+        bases = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), R))
+        q = lambda lo, hi: bytes(rng.integers(lo + 33, hi + 33, size=R).astype(np.uint8))
+        haps = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) for n in (300, 200, 37)]
+        b3 = synth.phmm_from_regions([([(bases, q(6, 42), q(39, 46), q(39, 46), bytes([43]) * R)], haps)])
+        s_ref, l_ref = oracle.phmm_batch(b3, 0)
+        dev = ctx.phmm_batch(b3, agx.PHMM_F64)
+        dev.launch()
+        l, s = dev.results()
+        dev.close()
+        assert np.array_equal(s, s_ref) and np.array_equal(l, l_ref)
+        assert relerr(ctx.phmm_forward(b3, agx.PHMM_F64_FMA), l_ref) <= 1e-12
+        assert relerr(ctx.phmm_forward(b3, agx.PHMM_F32_FMA), l_ref) <= 1e-6
 
 
 def test_gatk_prior_option(ctx, oracle, golden_dir):

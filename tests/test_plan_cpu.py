@@ -150,3 +150,17 @@ def test_phmm_planner_wide_window_and_pieces(prec):
     i = p.info()
     p.close()
     assert i.n_pairs == 40 * 48 * 14 and i.cells == big.cells() and i.cells / i.padded_cells > 0.65
+
+
+def test_longest_read_plans_in_every_precision():
+    """A read of AGX_PHMM_MAX_READ_LEN = 4096 rows: its table takes most of the 160 KB LDS with the 33-byte rows of
+    phmm_fill and would not fit with the 56-byte rows of the looked-up-prior fill, which is therefore not chosen."""
+    rng = np.random.default_rng(5)
+    bases = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 4096))
+    q = bytes([40 + 33]) * 4096
+    hap = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 300))
+    b = synth.phmm_from_regions([([(bases, q, q, q, bytes([10 + 33]) * 4096)], [hap, hap[:200]])])
+    for prec in (agx.PHMM_F64, agx.PHMM_F64_FMA, agx.PHMM_F32, agx.PHMM_F32_FMA):
+        p = agx.PhmmBatchDev(None, b, prec)
+        assert p.info().n_pairs == 2 and p.info().cells == 4096 * 500
+        p.close()
