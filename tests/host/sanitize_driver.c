@@ -92,6 +92,49 @@ static void phmm_file(const char *dir, const char *name)
     agx_phmm_text_free(t);
 }
 
+/* Synthetic PairHMM batches large enough for the planner's threaded passes (shape counts in the dense table / through
+ * the map, waves filled on several pieces of the pair list): plan-only, every precision. */
+static uint32_t lcg(uint32_t *s) { return *s = *s * 1664525u + 1013904223u; }
+static void phmm_synthetic(uint32_t n_regions, uint32_t reads_per, uint32_t haps_per, uint32_t r_lo, uint32_t r_hi, uint32_t h_lo,
+                           uint32_t h_hi, int other_letters)
+{
+    uint32_t seed = 12345u + n_regions + r_hi + h_hi;
+    const uint32_t nr = n_regions * reads_per, nh = n_regions * haps_per;
+    uint64_t *roff = calloc(nr + 1, sizeof *roff), *hoff = calloc(nh + 1, sizeof *hoff);
+    uint32_t *rreg = calloc(n_regions + 1, sizeof *rreg), *hreg = calloc(n_regions + 1, sizeof *hreg);
+    for (uint32_t r = 0; r < nr; r++) roff[r + 1] = roff[r] + r_lo + lcg(&seed) % (r_hi - r_lo + 1);
+    for (uint32_t h = 0; h < nh; h++) hoff[h + 1] = hoff[h] + h_lo + lcg(&seed) % (h_hi - h_lo + 1);
+    for (uint32_t g = 0; g <= n_regions; g++) {
+        rreg[g] = g * reads_per;
+        hreg[g] = g * haps_per;
+    }
+    uint8_t *rb = malloc(roff[nr] + 1), *q = malloc(roff[nr] + 1), *hb = malloc(hoff[nh] + 1);
+    for (uint64_t k = 0; k < roff[nr]; k++) {
+        rb[k] = (uint8_t)"ACGTN"[lcg(&seed) % 5u];
+        q[k] = (uint8_t)(33 + 10 + lcg(&seed) % 30u);
+    }
+    for (uint64_t k = 0; k < hoff[nh]; k++) hb[k] = (uint8_t)(other_letters ? "ACGTNacgt"[lcg(&seed) % 9u] : "ACGT"[lcg(&seed) % 4u]);
+    agx_phmm_desc d;
+    memset(&d, 0, sizeof d);
+    d.read_bases = rb, d.q_base = q, d.q_ins = q, d.q_del = q, d.q_gcp = q;
+    d.read_off = roff, d.n_reads = nr;
+    d.hap_bases = hb, d.hap_off = hoff, d.n_haps = nh;
+    d.region_read = rreg, d.region_hap = hreg, d.n_regions = n_regions;
+    for (int prec = 0; prec < 4; prec++) {
+        agx_phmm_batch *b = NULL;
+        int rc = agx_phmm_batch_create(NULL, &d, prec, &b);
+        EXPECT(rc == AGX_OK && b);
+        agx_phmm_info info;
+        if (b) {
+            EXPECT(agx_phmm_batch_info(b, &info) == AGX_OK && info.n_pairs == (int64_t)n_regions * reads_per * haps_per &&
+                   info.padded_cells >= info.cells);
+            EXPECT(agx_phmm_batch_launch(b) == AGX_E_NODEVICE);
+            agx_phmm_batch_destroy(b);
+        }
+    }
+    free(rb), free(q), free(hb), free(roff), free(hoff), free(rreg), free(hreg);
+}
+
 int main(int argc, char **argv)
 {
     if (argc != 2) return 2;
@@ -104,6 +147,10 @@ int main(int argc, char **argv)
     }
     const char *ph[] = {"phmm_test.in", "phmm_10s.in", "phmm_synth.in", "phmm_far.in", "phmm_long.in"};
     for (size_t i = 0; i < sizeof ph / sizeof ph[0]; i++) phmm_file(argv[1], ph[i]);
+    phmm_synthetic(40, 48, 14, 50, 150, 280, 380, 0);   /* 26 880 mixed pairs: dense shape table, several pieces */
+    phmm_synthetic(40, 48, 14, 50, 150, 280, 380, 1);   /* ... with letters outside ACGT: the other double fill's tables */
+    phmm_synthetic(64, 32, 16, 100, 100, 300, 300, 0);  /* 32 768 pairs of one shape */
+    phmm_synthetic(30, 30, 30, 1, 1000, 1, 1900, 0);    /* 27 000 pairs over a wide window of lengths: the map */
     /* wrong formats fed to each reader must fail or parse without touching invalid memory */
     agx_phmm_text *pt = NULL;
     char path[1024];

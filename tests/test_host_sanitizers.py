@@ -1,4 +1,4 @@
-"""AddressSanitizer + UBSan over the host side of libagx (text readers, planners, packers) on the CPU
+"""AddressSanitizer + UBSan, and ThreadSanitizer, over the host side of libagx (text readers, planners, packers) on the CPU
 build: the device objects are linked unchanged, no device is touched (plan-only batches)."""
 import glob
 import os
@@ -12,13 +12,12 @@ PKG = os.path.join(ROOT, "accelerating-genomics_amd")
 CLANG = "/opt/rocm/lib/llvm/bin/clang"
 
 
-@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not present")
-def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
+def _run_driver(tmp_path, golden_dir, sanitizers, env_extra):
     import accelerating_genomics_amd.api as agx
 
     if not os.path.exists(os.path.join(PKG, "build", "agx_phmm_finish_kernel.o")):
         agx.build()
-    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+    san = ["-fsanitize=" + sanitizers, "-fno-omit-frame-pointer", "-g", "-O1"]
     inc = ["-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-DAGX_TUNING"]  # AGX_HOST_THREADS below
     objs = []
     for src in ("agx_runtime.cpp", "agx_sw.cpp", "agx_phmm.cpp"):
@@ -34,9 +33,20 @@ def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
     exe = str(tmp_path / "sanitize_driver")
     subprocess.run([CLANG + "++", *san, *objs, *dev, "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
                     "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
-               AGX_HOST_THREADS="4")
+    env = dict(os.environ, AGX_HOST_THREADS="4", **env_extra)
     r = subprocess.run([exe, golden_dir], capture_output=True, env=env, timeout=600)
     tail = (r.stdout + r.stderr).decode(errors="replace")[-3000:]
     assert r.returncode == 0 and b"SANITIZE_DRIVER_OK" in r.stdout, tail
-    assert b"runtime error" not in r.stderr and b"AddressSanitizer" not in r.stderr, tail
+    assert b"runtime error" not in r.stderr and b"Sanitizer" not in r.stderr, tail
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not present")
+def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
+    _run_driver(tmp_path, golden_dir, "address,undefined",
+                dict(ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="ROCm clang not present")
+def test_host_code_under_tsan(tmp_path, golden_dir):
+    """The threaded planners and readers (four pool threads) under ThreadSanitizer: no data race."""
+    _run_driver(tmp_path, golden_dir, "thread", dict(TSAN_OPTIONS="halt_on_error=1"))
