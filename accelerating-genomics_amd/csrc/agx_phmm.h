@@ -67,8 +67,11 @@ static const int kPhNumClasses = sizeof(kPhClasses) / sizeof(kPhClasses[0]);
 // for that arithmetic (too many VGPRs).  Rows: f64 reference order, f64 FMA, f32.  (Width 32 in double
 // runs the two-waves-per-SIMD build, tools/cal_f64_wide.py.)
 static const double kPhClassCost[3][19] = {
-    {1.656, 1.400, 1.307, 1.244, 1.218, 1.173, 1.124, 1.133, 1.109, 1.073, 1.073, 1.053, 1.051, 1.000, 1.011, 0, 0, 0, 0},
-    {1.752, 1.449, 1.330, 1.227, 1.193, 1.174, 1.124, 1.127, 1.108, 1.071, 1.071, 1.050, 1.032, 1.024, 1.000, 0, 0, 0, 0},
+    // (the two double rows: round 2c, measured with the looked-up-prior fill, profiles/r02w_cal_f64_lut.log; before, with
+    // phmm_fill: 1.656 1.400 1.307 1.244 1.218 1.173 1.124 1.133 1.109 1.073 1.073 1.053 1.051 1.000 1.011 and
+    // 1.752 1.449 1.330 1.227 1.193 1.174 1.124 1.127 1.108 1.071 1.071 1.050 1.032 1.024 1.000)
+    {1.569, 1.330, 1.232, 1.176, 1.144, 1.101, 1.096, 1.071, 1.058, 1.060, 1.035, 1.053, 1.005, 1.000, 1.015, 0, 0, 0, 0},
+    {1.801, 1.457, 1.331, 1.258, 1.185, 1.136, 1.089, 1.099, 1.073, 1.086, 1.050, 1.066, 1.007, 1.017, 1.000, 0, 0, 0, 0},
     {1.872, 1.500, 1.346, 1.248, 1.184, 1.158, 1.132, 1.109, 1.090, 1.075, 1.090, 1.068, 1.045, 1.023, 1.011, 1.000, 1.071, 1.056, 1.045},
 };
 
