@@ -442,7 +442,7 @@ def main():
 
         out["config4"] = dict(c4_leg, metric="Smith-Waterman GCUPS, mixed lengths 32-512 (config 4: 1 048 576 pairs over 8 GPUs; weak leg: %d pairs per GPU)" % (C4_PAIRS // 8),
                               unit="GCUPS", launches_per_step=c4_info.n_launches, useful_cell_fraction=c4_info.cells / max(1, c4_info.padded_cells),
-                              score_checksum=c4_sum, roofline=roof(c4.algorithmic_bytes(), c4_t["launch_ms"], None),
+                              score_checksum=c4_sum, roofline=roof(c4.algorithmic_bytes(), c4_t["launch_ms"], "sw_fill_c4shard"),
                               total=dict(strong(s4_t, s4_rows, c4f.cells(sentinel=False) / 1e9, "GCUPS", "cells"),
                                          workload="ONE batch of 1 048 576 pairs U[32,512] cut into %d shards by cells (agx_sw_shard_cuts)" % world,
                                          launches_per_step_rank0=s4_info.n_launches, useful_cell_fraction_rank0=s4_info.cells / max(1, s4_info.padded_cells)),
@@ -450,7 +450,7 @@ def main():
         out["config5"] = dict(c5_leg, metric="PairHMM forward pairs/s, fp64 in the reference's operation order (config 5: 262 144 pairs R=250 H=500 over 8 GPUs; weak leg: %d pairs per GPU)" % c5.n_pairs,
                               unit="pairs/s", dtype="f64", gcups=n_gpus * c5.cells() * c5_t["steps"] / c5_t["dt"] / 1e9,
                               launches_per_step=c5_info.n_launches, useful_cell_fraction=c5_info.cells / max(1, c5_info.padded_cells),
-                              log10_checksum=c5_sum, roofline=roof(c5.algorithmic_bytes(), c5_t["launch_ms"], None),
+                              log10_checksum=c5_sum, roofline=roof(c5.algorithmic_bytes(), c5_t["launch_ms"], "phmm_fill_c5shard"),
                               valu={"ops_per_cell": "12 instructions per cell: the reference's 11 fp64 operations in its order (7 v_mul_f64, 4 v_add_f64) + "
                                                     "v_add_u32_sdwa (the prior is read from the read's LDS table, ds_read_b64)",
                                     "frac_of_instruction_mix_ceiling": c5_info.padded_cells * (12 / VALU_PACKED) / (c5_t["launch_ms"] * 1e-3)},
