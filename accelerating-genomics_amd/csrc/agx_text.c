@@ -6,6 +6,7 @@
  * so the drop-in command lines see exactly the pairs the reference programs see.
  */
 #include <errno.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -601,13 +602,13 @@ void agx_phmm_text_free(agx_phmm_text *t)
 
 #define PHMM_LINE (1000 * 5 + 1) /* MAX_READ_LEN*5+1, antidiagsPairHMM.c:8,353 */
 
-/* next whitespace-delimited token of s (sscanf "%s" rule); returns its length, *tok its start */
-static size_t next_token(const char **s, const char **tok)
+/* next whitespace-delimited token of [*s, end) (sscanf "%s" rule); returns its length, *tok its start */
+static size_t next_token(const char **s, const char *end, const char **tok)
 {
     const char *p = *s;
-    while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r') p++;
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) p++;
     *tok = p;
-    while (*p && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) p++;
+    while (p < end && !(*p == ' ' || *p == '\t' || *p == '\n' || *p == '\v' || *p == '\f' || *p == '\r')) p++;
     *s = p;
     return (size_t)(p - *tok);
 }
@@ -618,10 +619,24 @@ static size_t next_token(const char **s, const char **tok)
  * pairs (at least one region), as a fresh agx_phmm_text the caller frees.  State that the reference
  * keeps across loop turns stays in the reader: nr / nh survive a malformed header line (sscanf leaves
  * them untouched, :378).
+ *
+ * Lines come from a block buffer with the reference's fgets(line, 5001, f) rule (at most 5000 bytes a call, a line
+ * ends behind its newline; what a line holds is what strcspn(line, "\n") / strlen leave of it: up to the first
+ * newline or NUL).  One pass walks the region structure -- headers, line counts, the region cut short at the end of
+ * the file -- and only notes where every read line lies (its bytes go to a store of the chunk); the read lines are
+ * then cut into their five fields and copied into the tracks by the host thread pool, every line at the offset the
+ * prefix sum of the read lengths gives it (round 2c: the one-threaded reader, two copies and four scans per byte,
+ * fed 8 M pairs/s of config 5's shape where the device takes 21 M in double).
  */
+#define PHMM_BLOCK ((size_t)4 << 20)
 struct agx_phmm_reader {
     FILE *f;
-    char *line;
+    /* the text of the chunk being read: [pos, end) of buf is unread; next() takes the file in blocks of PHMM_BLOCK
+     * bytes behind `end`, notes the read lines where they lie (no copy) and moves what it did not consume to the front
+     * for the next chunk */
+    char *buf;
+    size_t pos, end, cap;
+    int eof;
     int nr, nh;
     int finished;
     uint32_t regions_done; /* complete regions handed out so far (for error messages) */
@@ -631,7 +646,7 @@ void agx_phmm_reader_close(agx_phmm_reader *r)
 {
     if (!r) return;
     if (r->f) fclose(r->f);
-    free(r->line);
+    free(r->buf);
     free(r);
 }
 
@@ -647,24 +662,110 @@ int agx_phmm_reader_open(const char *path, agx_phmm_reader **out)
         agx_set_error("agx_phmm_reader_open: out of memory");
         return AGX_E_NOMEM;
     }
-    r->line = (char *)malloc(PHMM_LINE);
+    r->cap = 2 * PHMM_BLOCK;
+    r->buf = (char *)malloc(r->cap);
     r->f = fopen(path, "r");
     if (!r->f) {
         agx_set_error("Error opening input file_r: %s", strerror(errno));
         agx_phmm_reader_close(r);
         return AGX_E_IO;
     }
-    if (!r->line) {
+    if (!r->buf) {
         agx_set_error("agx_phmm_reader_open: out of memory");
         agx_phmm_reader_close(r);
         return AGX_E_NOMEM;
     }
-    setvbuf(r->f, NULL, _IOFBF, (size_t)1 << 20);
+    setvbuf(r->f, NULL, _IONBF, 0); /* the reader has its own block buffer */
     *out = r;
     return AGX_OK;
 }
 
 int agx_phmm_reader_done(const agx_phmm_reader *r) { return !r || r->finished; }
+
+/* fgets(line, PHMM_LINE, f): the next at most PHMM_LINE - 1 bytes up to and including a newline; 0 at the end of the
+ * file, (size_t)-1 out of memory.  The line starts at buf + *off (the buffer may move when it grows: offsets, not
+ * pointers, are what a chunk keeps). */
+static size_t phmm_next_line(agx_phmm_reader *r, size_t *off)
+{
+    if (r->end - r->pos < (size_t)PHMM_LINE && !r->eof) {
+        if (r->cap - r->end < PHMM_BLOCK) {
+            size_t cap = r->cap;
+            while (cap - r->end < PHMM_BLOCK) cap *= 2;
+            char *q = (char *)realloc(r->buf, cap);
+            if (!q) return (size_t)-1;
+            r->buf = q;
+            r->cap = cap;
+        }
+        while (r->end - r->pos < (size_t)PHMM_LINE && !r->eof) {
+            const size_t got = fread(r->buf + r->end, 1, PHMM_BLOCK, r->f);
+            if (got == 0) r->eof = 1;
+            r->end += got;
+        }
+    }
+    size_t avail = r->end - r->pos;
+    if (avail == 0) return 0;
+    if (avail > (size_t)PHMM_LINE - 1) avail = (size_t)PHMM_LINE - 1;
+    const char *s = r->buf + r->pos;
+    const char *nl = (const char *)memchr(s, '\n', avail);
+    const size_t n = nl ? (size_t)(nl - s) + 1 : avail;
+    *off = r->pos;
+    r->pos += n;
+    return n;
+}
+
+/* what strcspn(line, "\n") leaves of a line fgets returned: the bytes before the first newline or NUL */
+static size_t phmm_line_text(const char *s, size_t n)
+{
+    if (n && s[n - 1] == '\n') n--;
+    const char *z = (const char *)memchr(s, 0, n);
+    return z ? (size_t)(z - s) : n;
+}
+
+typedef struct {
+    const char *raw;
+    const uint64_t *line_off; /* read line i = raw[line_off[i] .. line_off[i] + line_len[i]) */
+    const uint32_t *line_len;
+    const uint64_t *roff; /* n_lines + 1: where its bases go in the tracks */
+    unsigned char *trk[5];
+    uint32_t n_lines;
+    int parts;
+    int64_t first_bad; /* smallest line index with an error; -1 = none */
+    int bad_kind[1];   /* 1: line too short; 2 + k: field k too short */
+    pthread_mutex_t mu;
+} phmm_cut_job;
+
+static void phmm_cut_part(int part, void *arg)
+{
+    phmm_cut_job *j = (phmm_cut_job *)arg;
+    const uint32_t per = (j->n_lines + (uint32_t)j->parts - 1) / (uint32_t)j->parts;
+    const uint32_t lo = (uint32_t)part * per, hi = lo + per < j->n_lines ? lo + per : j->n_lines;
+    for (uint32_t i = lo; i < hi; i++) {
+        const char *s = j->raw + j->line_off[i], *end = s + j->line_len[i];
+        const size_t sl = j->line_len[i];
+        int kind = 0;
+        if (sl < 4) /* (strlen-4)/5 underflows in the reference (:418) */
+            kind = 1;
+        else {
+            const size_t n = (sl - 4) / 5;
+            const char *p = s, *tok[5];
+            size_t tl[5];
+            for (int k = 0; k < 5; k++) tl[k] = next_token(&p, end, &tok[k]);
+            for (int k = 0; k < 5 && !kind; k++)
+                if (tl[k] < n) kind = 2 + k;
+            if (!kind)
+                for (int k = 0; k < 5; k++) memcpy(j->trk[k] + j->roff[i], tok[k], n);
+        }
+        if (kind) {
+            pthread_mutex_lock(&j->mu);
+            if (j->first_bad < 0 || (int64_t)i < j->first_bad) {
+                j->first_bad = (int64_t)i;
+                j->bad_kind[0] = kind;
+            }
+            pthread_mutex_unlock(&j->mu);
+            return; /* lines behind an error of this part cannot come first */
+        }
+    }
+}
 
 int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **out)
 {
@@ -675,41 +776,52 @@ int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **
     *out = NULL;
     int rc = AGX_E_NOMEM;
     phmm_text_impl *m = (phmm_text_impl *)calloc(1, sizeof *m);
-    char *line = r->line;
-    char **rl = NULL;
+    buf_t line_off = {0}, line_len = {0}; /* where every read line of the chunk lies in the reader's buffer */
     int nr = r->nr, nh = r->nh;
     uint64_t z64 = 0;
     uint32_t z32 = 0;
     uint32_t n_reads = 0, n_haps = 0, n_regions = 0;
+    size_t line = 0, ln = 0;
     if (!m) goto done;
-    if (buf_put(&m->roff, &z64, 8) || buf_put(&m->hoff, &z64, 8) || buf_put(&m->rreg, &z32, 4) || buf_put(&m->hreg, &z32, 4)) goto done;
+    if (r->pos) { /* what the last chunk left unread moves to the front */
+        memmove(r->buf, r->buf + r->pos, r->end - r->pos);
+        r->end -= r->pos;
+        r->pos = 0;
+    }
+    if (buf_put(&m->hoff, &z64, 8) || buf_put(&m->rreg, &z32, 4) || buf_put(&m->hreg, &z32, 4)) goto done;
     while (!r->finished && (n_regions == 0 || m->pub.n_pairs < max_pairs)) {
-        if (!fgets(line, PHMM_LINE, r->f)) { /* :375 */
+        if ((ln = phmm_next_line(r, &line)) == (size_t)-1) goto done;
+        if (!ln) { /* :375 */
             r->finished = 1;
             break;
         }
         m->pub.n_regions_seen++;
-        sscanf(line, "%d %d", &nr, &nh);
+        {
+            char head[PHMM_LINE]; /* the line as the C string fgets would have left */
+            const size_t hl = phmm_line_text(r->buf + line, ln);
+            memcpy(head, r->buf + line, hl);
+            head[hl] = 0;
+            sscanf(head, "%d %d", &nr, &nh);
+        }
         if (nr < 0) nr = 0;
         if (nh < 0) nh = 0;
         /* the reference reads the haplotypes first through a second stream (:389-407) and fails
          * with "Error reading haplotypes." when the region is cut short: nothing of it is output */
-        rl = (char **)calloc((size_t)nr + 1, sizeof(char *));
-        if (!rl) goto done;
-        int got_r = 0, got_h = 0, bad = 0;
+        int got_r = 0, got_h = 0;
+        const size_t lo_mark = line_off.n, ll_mark = line_len.n;
         for (; got_r < nr; got_r++) {
-            if (!fgets(line, PHMM_LINE, r->f)) break;
-            line[strcspn(line, "\n")] = 0; /* :417 */
-            rl[got_r] = strdup(line);
-            if (!rl[got_r]) goto done;
+            if ((ln = phmm_next_line(r, &line)) == (size_t)-1) goto done;
+            if (!ln) break;
+            const uint64_t o = line;
+            const uint32_t l = (uint32_t)phmm_line_text(r->buf + line, ln); /* :417 */
+            if (buf_put(&line_off, &o, 8) || buf_put(&line_len, &l, 4)) goto done;
         }
         const size_t hb_mark = m->hb.n, hoff_mark = m->hoff.n;
         if (got_r == nr) {
             for (; got_h < nh; got_h++) {
-                if (!fgets(line, PHMM_LINE, r->f)) break;
-                line[strcspn(line, "\n")] = 0; /* :399 */
-                size_t n = strlen(line);
-                if (buf_put(&m->hb, line, n)) goto done;
+                if ((ln = phmm_next_line(r, &line)) == (size_t)-1) goto done;
+                if (!ln) break;
+                if (buf_put(&m->hb, r->buf + line, phmm_line_text(r->buf + line, ln))) goto done; /* :399 */
                 uint64_t o = m->hb.n;
                 if (buf_put(&m->hoff, &o, 8)) goto done;
             }
@@ -717,39 +829,9 @@ int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **
         if (got_r < nr || got_h < nh) {
             m->hb.n = hb_mark;
             m->hoff.n = hoff_mark;
+            line_off.n = lo_mark;
+            line_len.n = ll_mark;
             m->pub.truncated = 1;
-            bad = 1;
-        }
-        const size_t rb_mark = m->rb.n, roff_mark = m->roff.n;
-        for (int i = 0; i < nr && !bad; i++) {
-            size_t sl = strlen(rl[i]);
-            if (sl < 4) { /* (strlen-4)/5 underflows in the reference (:418) */
-                agx_set_error("region %u, read %d: line too short to hold five fields", r->regions_done + n_regions + 1, i);
-                rc = AGX_E_IO;
-                goto done;
-            }
-            size_t n = (sl - 4) / 5;
-            const char *p = rl[i], *tok[5];
-            size_t tl[5];
-            for (int k = 0; k < 5; k++) tl[k] = next_token(&p, &tok[k]);
-            for (int k = 0; k < 5; k++)
-                if (tl[k] < n) {
-                    agx_set_error("region %u, read %d: field %d shorter than the read length %zu", r->regions_done + n_regions + 1, i, k, n);
-                    rc = AGX_E_IO;
-                    goto done;
-                }
-            if (buf_put(&m->rb, tok[0], n) || buf_put(&m->qb, tok[1], n) || buf_put(&m->qi, tok[2], n) ||
-                buf_put(&m->qd, tok[3], n) || buf_put(&m->qg, tok[4], n))
-                goto done;
-            uint64_t o = m->rb.n;
-            if (buf_put(&m->roff, &o, 8)) goto done;
-        }
-        for (int i = 0; i < nr; i++) free(rl[i]);
-        free(rl);
-        rl = NULL;
-        if (bad) {
-            m->rb.n = m->qb.n = m->qi.n = m->qd.n = m->qg.n = rb_mark;
-            m->roff.n = roff_mark;
             r->finished = 1;
             break;
         }
@@ -758,6 +840,58 @@ int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **
         n_regions++;
         if (buf_put(&m->rreg, &n_reads, 4) || buf_put(&m->hreg, &n_haps, 4)) goto done;
         m->pub.n_pairs += (int64_t)nr * nh;
+    }
+    /* ---- the read lines -> five tracks: lengths and offsets first, then the cutting and copying, threaded */
+    {
+        const uint64_t *lo = (const uint64_t *)line_off.p;
+        const uint32_t *ll = (const uint32_t *)line_len.p;
+        if (buf_reserve(&m->roff, ((size_t)n_reads + 1) * 8)) goto done;
+        uint64_t *roff = (uint64_t *)m->roff.p;
+        roff[0] = 0;
+        for (uint32_t i = 0; i < n_reads; i++) {
+            const uint64_t sl = ll[i];
+            roff[i + 1] = roff[i] + (sl < 4 ? 0 : (sl - 4) / 5);
+        }
+        m->roff.n = ((size_t)n_reads + 1) * 8;
+        const size_t total = (size_t)roff[n_reads];
+        buf_t *trk[5] = {&m->rb, &m->qb, &m->qi, &m->qd, &m->qg};
+        for (int k = 0; k < 5; k++) {
+            if (buf_reserve(trk[k], total ? total : 1)) goto done;
+            trk[k]->n = total;
+        }
+        phmm_cut_job j;
+        memset(&j, 0, sizeof j);
+        j.raw = r->buf;
+        j.line_off = lo;
+        j.line_len = ll;
+        j.roff = roff;
+        for (int k = 0; k < 5; k++) j.trk[k] = trk[k]->p;
+        j.n_lines = n_reads;
+        j.first_bad = -1;
+        j.parts = agx_host_threads_c();
+        if ((uint32_t)j.parts > n_reads / 256u + 1u) j.parts = (int)(n_reads / 256u + 1u);
+        pthread_mutex_init(&j.mu, NULL);
+        if (j.parts <= 1) {
+            j.parts = 1;
+            phmm_cut_part(0, &j);
+        } else
+            agx_pool_run_c(j.parts, phmm_cut_part, &j);
+        pthread_mutex_destroy(&j.mu);
+        if (j.first_bad >= 0) {
+            const uint32_t *rreg = (const uint32_t *)m->rreg.p;
+            uint32_t g = 0;
+            while (g + 1 < n_regions && rreg[g + 1] <= (uint32_t)j.first_bad) g++;
+            const int i = (int)((uint32_t)j.first_bad - rreg[g]);
+            if (j.bad_kind[0] == 1)
+                agx_set_error("region %u, read %d: line too short to hold five fields", r->regions_done + g + 1, i);
+            else {
+                const uint64_t sl = ll[j.first_bad];
+                agx_set_error("region %u, read %d: field %d shorter than the read length %zu", r->regions_done + g + 1, i, j.bad_kind[0] - 2,
+                              (size_t)((sl - 4) / 5));
+            }
+            rc = AGX_E_IO;
+            goto done;
+        }
     }
     m->pub.desc.read_bases = m->rb.p;
     m->pub.desc.q_base = m->qb.p;
@@ -777,10 +911,8 @@ int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **
 done:
     r->nr = nr;
     r->nh = nh;
-    if (rl) {
-        for (int i = 0; i < nr; i++) free(rl[i]);
-        free(rl);
-    }
+    free(line_off.p);
+    free(line_len.p);
     if (rc == AGX_E_NOMEM) agx_set_error("agx_phmm_reader_next: out of memory");
     if (rc != AGX_OK) {
         agx_phmm_text_free(m ? &m->pub : NULL);

@@ -224,6 +224,145 @@ def test_phmm_reader_truncated_region_ends_the_stream(tmp_path, golden_dir):
     assert [(c[0].n_regions, c[1], c[2]) for c in chunks] == [(1, 1, 0), (0, 1, 1)]
 
 
+def _phmm_reference_reading_model(data: bytes):
+    """The reference's reading of a PairHMM file byte for byte (antidiagsPairHMM.c:353-433): fgets into a 5001-byte
+    buffer, strcspn(line, "\n") / C-string ends, a header's sscanf("%d %d") leaving nr / nh untouched where it fails,
+    the region cut short by the end of the file, (strlen - 4) / 5 bases per read line and its five sscanf("%s") fields.
+    -> ("ok", regions, headers seen, truncated) or ("err", region number, read index, kind)."""
+    import re
+
+    pos = 0
+
+    def fgets():
+        nonlocal pos
+        if pos >= len(data):
+            return None
+        piece = data[pos:pos + 5000]
+        k = piece.find(b"\n")
+        if k >= 0:
+            piece = piece[:k + 1]
+        pos += len(piece)
+        return piece
+
+    def text(line):
+        k = line.find(b"\n")
+        line = line if k < 0 else line[:k]
+        z = line.find(b"\0")
+        return line if z < 0 else line[:z]
+
+    nr = nh = 0
+    regions, seen, truncated = [], 0, 0
+    while True:
+        head = fgets()
+        if head is None:
+            break
+        seen += 1
+        m = re.match(rb"[ \t\n\v\f\r]*([+-]?\d+)(?:[ \t\n\v\f\r]*([+-]?\d+))?", text(head))
+        if m:
+            nr = int(m.group(1))
+            if m.group(2) is not None:
+                nh = int(m.group(2))
+        nr, nh = max(nr, 0), max(nh, 0)
+        reads, haps = [], []
+        while len(reads) < nr:
+            line = fgets()
+            if line is None:
+                break
+            reads.append(text(line))
+        if len(reads) == nr:
+            while len(haps) < nh:
+                line = fgets()
+                if line is None:
+                    break
+                haps.append(text(line))
+        if len(reads) < nr or len(haps) < nh:
+            truncated = 1
+            break
+        tracks = []
+        for i, line in enumerate(reads):
+            if len(line) < 4:
+                return ("err", len(regions) + 1, i, "line too short")
+            n = (len(line) - 4) // 5
+            tok = re.findall(rb"[^ \t\n\v\f\r]+", line)[:5]
+            tok += [b""] * (5 - len(tok))
+            for k in range(5):
+                if len(tok[k]) < n:
+                    return ("err", len(regions) + 1, i, "field %d shorter" % k)
+            tracks.append(tuple(t[:n] for t in tok))
+        regions.append((tracks, haps))
+    return ("ok", regions, seen, truncated)
+
+
+def _nasty_phmm_files():
+    rng = np.random.default_rng(7)
+    seq = lambda n, alpha=b"ACGTN": bytes(rng.choice(np.frombuffer(alpha, np.uint8), n))
+    q = lambda n: bytes(rng.integers(34, 80, size=n).astype(np.uint8))
+    readline = lambda n, sep=b" ": sep.join([seq(n), q(n), q(n), q(n), q(n)])
+
+    def region(nr, nh, R, H, sep=b" ", nl=b"\n"):
+        out = [b"%d %d" % (nr, nh)]
+        out += [readline(int(rng.integers(1, R + 1)), sep) for _ in range(nr)]
+        out += [seq(int(rng.integers(1, H + 1)), b"ACGT") for _ in range(nh)]
+        return nl.join(out) + nl
+
+    f = {}
+    f["plain"] = b"".join(region(int(rng.integers(1, 6)), int(rng.integers(1, 5)), 60, 90) for _ in range(40))
+    f["nofinalnl"] = f["plain"][:-1]
+    f["crlf"] = b"".join(region(2, 2, 30, 40, nl=b"\r\n") for _ in range(5))
+    f["tabs"] = b"".join(region(3, 2, 30, 40, sep=b" \t ") for _ in range(5))
+    f["longhap"] = b"2 2\n" + readline(50) + b"\n" + readline(70) + b"\n" + seq(6000, b"ACGT") + b"\n" + seq(12001, b"ACGT") + b"\n" + region(2, 2, 20, 20)
+    f["longread"] = (b"1 1\n" + readline(999) + b"\n" + seq(100, b"ACGT") + b"\n1 1\n" + readline(1000) + b"\n" + seq(100, b"ACGT") +
+                     b"\n1 1\n" + readline(1200) + b"\n" + seq(50, b"ACGT") + b"\n" + region(1, 1, 10, 10))
+    f["exact5000"] = b"1 2\n" + readline(30) + b"\n" + seq(5000, b"ACGT") + b"\n" + seq(4999, b"ACGT") + b"\n" + region(1, 1, 10, 10)
+    f["nul"] = (b"2 2\n" + readline(20) + b"\n" + readline(25)[:40] + b"\0" + readline(25)[40:] + b"\n" + seq(30, b"ACGT") + b"\nACG\0TTT\n" +
+                region(1, 2, 10, 10))
+    f["trunc_reads"] = region(2, 2, 20, 30) + b"3 2\n" + readline(10) + b"\n"
+    f["trunc_haps"] = region(2, 2, 20, 30) + b"2 3\n" + readline(10) + b"\n" + readline(12) + b"\n" + seq(20, b"ACGT") + b"\n"
+    f["badheader"] = (region(2, 2, 20, 30) + b"x y\n" + readline(10) + b"\n" + readline(12) + b"\n" + seq(20, b"ACGT") + b"\n" + seq(22, b"ACGT") +
+                      b"\n" + region(1, 1, 10, 10))
+    f["half_header"] = region(2, 3, 20, 30) + b"1\n" + readline(9) + b"\n" + seq(5, b"ACGT") + b"\n" + seq(6, b"ACGT") + b"\n" + seq(7, b"ACGT") + b"\n"
+    f["emptyline_header"] = region(1, 1, 20, 30) + b"\n" + readline(10) + b"\n" + seq(20, b"ACGT") + b"\n"
+    f["zero_counts"] = b"0 2\nACGT\nACG\n" + region(1, 1, 10, 10) + b"2 0\n" + readline(5) + b"\n" + readline(6) + b"\n" + region(1, 1, 10, 10)
+    f["negative"] = b"-1 2\nACGT\nACG\n" + region(1, 1, 10, 10)
+    f["shortline"] = region(1, 1, 10, 10) + b"1 1\nAB\nACGT\n"
+    f["shortfield"] = region(1, 1, 10, 10) + b"1 1\nACGTACGT II II II II\nACGT\n"
+    f["empty"] = b""
+    f["onlyheader"] = b"3 3\n"
+    f["extra_fields"] = b"1 1\n" + readline(10) + b" extra stuff\n" + seq(10, b"ACGT") + b"\n"
+    f["spaces_hap"] = b"1 2\n" + readline(10) + b"\nACGT ACGT\n  ACG\n"
+    f["many"] = b"".join(region(12, 3, 120, 200) for _ in range(120))  # enough read lines for several threads
+    return f
+
+
+@pytest.mark.parametrize("max_pairs", [1, 7, 1 << 40])
+def test_phmm_reader_against_the_byte_level_model(tmp_path, max_pairs):
+    """agx_phmm_reader_* (block buffer with fgets' rule, read lines cut into their fields by the thread pool) against a
+    byte-level model of the reference's reading, on files with every irregularity the format allows: lines beyond the
+    5000-byte buffer, NUL bytes, CR LF, tabs, no final newline, malformed and half headers, zero and negative counts,
+    regions cut short, short lines and fields (errors name the region and the read the reference would trip on)."""
+    for name, data in _nasty_phmm_files().items():
+        path = str(tmp_path / (name + ".in"))
+        open(path, "wb").write(data)
+        want = _phmm_reference_reading_model(data)
+        try:
+            chunks = list(agx.read_phmm_text_chunks(path, max_pairs))
+        except agx.AgxError as e:
+            assert want[0] == "err" and e.code == agx.E_IO, (name, want[:1], str(e))
+            assert "region %d, read %d:" % (want[1], want[2]) in str(e) and want[3] in str(e), (name, want, str(e))
+            continue
+        assert want[0] == "ok", (name, want)
+        _, regions, seen, truncated = want
+        assert sum(c[1] for c in chunks) == seen and max([c[2] for c in chunks] + [0]) == truncated, name
+        got = []
+        for b, _, _ in chunks:
+            for g in range(b.n_regions):
+                reads = [tuple(x[int(b.roff[r]):int(b.roff[r + 1])].tobytes() for x in (b.read_bases, b.q_base, b.q_ins, b.q_del, b.q_gcp))
+                         for r in range(int(b.rreg[g]), int(b.rreg[g + 1]))]
+                haps = [b.hap_bases[int(b.hoff[h]):int(b.hoff[h + 1])].tobytes() for h in range(int(b.hreg[g]), int(b.hreg[g + 1]))]
+                got.append((reads, haps))
+        assert got == regions, name
+
+
 def test_shard_cut_rules_match_the_python_mirror():
     """agx_sw_shard_cuts / agx_phmm_shard_cuts (what agx_*_devices and bench.py's strong-scaling leg cut by) against
     dist.shard_bounds, the rule bench.py's ranks use: contiguous, balanced by cells, every unit in exactly one shard."""
