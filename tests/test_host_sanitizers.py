@@ -50,3 +50,14 @@ def test_host_code_under_asan_ubsan(tmp_path, golden_dir):
 def test_host_code_under_tsan(tmp_path, golden_dir):
     """The threaded planners and readers (four pool threads) under ThreadSanitizer: no data race."""
     _run_driver(tmp_path, golden_dir, "thread", dict(TSAN_OPTIONS="halt_on_error=1"))
+
+
+def test_fast_f6_formatter_is_printf(tmp_path):
+    """host/agx_fmt.h writes "%f\\n" for the PairHMM command line: byte for byte snprintf's output on special values,
+    every multiple of 2^-7 and 2^-12 around zero and its neighbours (exact ties, near-ties), likelihood-like values,
+    decimal near-ties, large values and random bit patterns (tests/host/fmt_check.c; 2.4 million values here)."""
+    exe = str(tmp_path / "fmt_check")
+    subprocess.run(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-D_DEFAULT_SOURCE", "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+                    "-I" + os.path.join(PKG, "host"), os.path.join(ROOT, "tests", "host", "fmt_check.c"), "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe, "300000"], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"FMT_CHECK_OK" in r.stdout, (r.stdout + r.stderr).decode(errors="replace")[-2000:]
