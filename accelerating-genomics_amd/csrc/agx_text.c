@@ -687,7 +687,7 @@ int agx_phmm_reader_done(const agx_phmm_reader *r) { return !r || r->finished; }
  * pointers, are what a chunk keeps). */
 static size_t phmm_next_line(agx_phmm_reader *r, size_t *off)
 {
-    if (r->end - r->pos < (size_t)PHMM_LINE && !r->eof) {
+    while (r->end - r->pos < (size_t)PHMM_LINE && !r->eof) {
         if (r->cap - r->end < PHMM_BLOCK) {
             size_t cap = r->cap;
             while (cap - r->end < PHMM_BLOCK) cap *= 2;
@@ -696,11 +696,9 @@ static size_t phmm_next_line(agx_phmm_reader *r, size_t *off)
             r->buf = q;
             r->cap = cap;
         }
-        while (r->end - r->pos < (size_t)PHMM_LINE && !r->eof) {
-            const size_t got = fread(r->buf + r->end, 1, PHMM_BLOCK, r->f);
-            if (got == 0) r->eof = 1;
-            r->end += got;
-        }
+        const size_t got = fread(r->buf + r->end, 1, PHMM_BLOCK, r->f);
+        if (got == 0) r->eof = 1;
+        r->end += got;
     }
     size_t avail = r->end - r->pos;
     if (avail == 0) return 0;
