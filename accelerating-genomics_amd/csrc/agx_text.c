@@ -331,6 +331,9 @@ int agx_sw_reader_next(agx_sw_reader *r, int64_t max_pairs, agx_sw_text **out)
             est = (size_t)((double)r->hint_bases / (double)r->hint_pairs * (double)want * 1.03) + 65536;
         else if (r->regular && (size_t)(r->size - r->pos) < est)
             est = (size_t)(r->size - r->pos);
+        /* an unbounded request (agx_sw_text_read) takes the rest of the file in one piece: the threaded branch below
+           reads `est` bytes and no more, so a smaller estimate would end the chunk early */
+        if (max_pairs == INT64_MAX && r->regular && r->size > r->pos) est = (size_t)(r->size - r->pos);
         const size_t carry = r->hi - r->lo;
         if (buf_reserve(&bases, carry + est + 4096)) goto done;
         if (carry) memcpy(bases.p, r->buf + r->lo, carry);
@@ -572,6 +575,14 @@ int agx_sw_text_read(const char *path, int line_buf, agx_sw_text **out)
     int rc = agx_sw_reader_open(path, line_buf, &r);
     if (rc != AGX_OK) return rc;
     rc = agx_sw_reader_next(r, INT64_MAX, out);
+    /* An unbounded request takes the whole file (the chunk's size estimate above is the rest of the file); should a
+       chunk ever end before the reference's loop would have, that is an error, never a silently shorter batch. */
+    if (rc == AGX_OK && !agx_sw_reader_done(r)) {
+        agx_sw_text_free(*out);
+        *out = NULL;
+        agx_set_error("agx_sw_text_read: the reader stopped before the end of the input");
+        rc = AGX_E_IO;
+    }
     agx_sw_reader_close(r);
     return rc;
 }

@@ -115,18 +115,23 @@ def cpu_baseline_sw_multicore(n_procs, pairs_each):
             "sample": "%d concurrent copies of antidiagonalSmithWaterman.c, %d pairs each, %.1f s" % (n_procs, pairs_each, dt)}
 
 
-def _phmm_ref_or_port(p, label):
+def _phmm_ref_or_port(p, label, program="phmm_matrix_ref"):
+    """Time a reference PairHMM program (or the oracle port) on the regions p, one core.  `program`:
+    phmm_matrix_ref = pairHMMmatrix.c, phmm_antidiag_ref = antidiagsPairHMM.c (the program north_star names; it
+    leaks 24 B per cell, antidiagsPairHMM.c:144-151, so its sample is kept to a few hundred pairs)."""
     import accelerating_genomics_amd.synth as synth
 
-    ref = os.path.join(ROOT, "oracle", "_ref", "phmm_matrix_ref")
+    ref = os.path.join(ROOT, "oracle", "_ref", program)
     if os.access(ref, os.X_OK):
         with tempfile.TemporaryDirectory() as d:
             path = os.path.join(d, "p.in")
             synth.write_phmm_file(path, p)
             t0 = time.perf_counter()
-            subprocess.run([ref, path, os.path.join(d, "p.out")], capture_output=True, check=True)
+            subprocess.run([ref, path, os.path.join(d, "p.out")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             dt = time.perf_counter() - t0
-        kind, what = "reference", "pairHMMmatrix.c (fp64; antidiagsPairHMM.c leaks 24 B/cell, SURVEY.md Q9)"
+        kind = "reference"
+        what = ("antidiagsPairHMM.c itself (fp64; leaks 24 B per cell, so the sample is small)" if program == "phmm_antidiag_ref"
+                else "pairHMMmatrix.c (fp64; same numbers as antidiagsPairHMM.c, no leak)")
     else:
         from tests import oracle_api
 
@@ -139,7 +144,39 @@ def _phmm_ref_or_port(p, label):
             "sample": "%s, %s, %.1f s" % (label, what, dt)}
 
 
-def main():
+def cpu_baseline_phmm_multicore(n_procs, regions_each):
+    """n_procs concurrent copies of pairHMMmatrix.c, each on its own file of config-3 regions."""
+    import accelerating_genomics_amd.synth as synth
+
+    ref = os.path.join(ROOT, "oracle", "_ref", "phmm_matrix_ref")
+    if not os.access(ref, os.X_OK):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        paths, pairs = [], 0
+        for k in range(n_procs):
+            p = synth.phmm_regions(regions_each, PH_READS, PH_HAPS, PH_R, PH_H, seed=300 + k)
+            pairs += p.n_pairs
+            path = os.path.join(d, "p%d.in" % k)
+            synth.write_phmm_file(path, p)
+            paths.append(path)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([ref, q, q + ".out"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for q in paths]
+        for pr in procs:
+            pr.wait()
+        dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": n_procs, "kind": "reference",
+            "sample": "%d concurrent copies of pairHMMmatrix.c, %d config-3 pairs each, %.1f s" % (n_procs, pairs // n_procs, dt)}
+
+
+def host_cores():
+    """Cores this process may run on (the box's share), not the machine's count."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -147,10 +184,76 @@ def main():
     ap.add_argument("--warm-seconds", type=float, default=0.5, help="back-to-back launches before every timed leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="headline legs only (PMC profiling passes)")
+    # The control plane (barriers, max of the ranks' clocks, the per-rank table: host scalars only) runs on gloo by
+    # default; "nccl" (= RCCL) puts the same three calls on device tensors.  The data path has no collective.
+    ap.add_argument("--dist-backend", default="gloo", choices=["nccl", "gloo"])
     # rehearsal of the multi-rank control flow on a box with fewer GPUs than ranks (never for numbers):
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--share-device", action="store_true", help="map every rank to device 0")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` run bare (no launcher, WORLD_SIZE unset): start the N ranks here -- one process per
+    GPU, the environment torch.distributed.run would give them -- relay rank 0's one JSON line and leave with the worst
+    return code.  This runs BEFORE torch or libagx are imported: the parent never makes a HIP call (a process that has
+    touched the GPU must not fork/exec launchers), it only waits."""
+    import socket
+
+    assert "torch" not in sys.modules and "accelerating_genomics_amd.api" not in sys.modules
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:
+        maps = ""
+    hip_mapped = any(lib in maps for lib in ("libamdhip64", "libagx", "libhsa-runtime64"))
+    assert not hip_mapped, "the launcher process has a HIP library mapped"
+    print("bench.py: WORLD_SIZE unset and --gpus %d: starting %d ranks (parent has imported torch: %s, libagx: %s, HIP libraries mapped: %s), "
+          "rendezvous 127.0.0.1:%d" % (args.gpus, args.gpus, "torch" in sys.modules, "accelerating_genomics_amd.api" in sys.modules, hip_mapped, port),
+          file=sys.stderr, flush=True)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AGX_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout is the JSON line; the other ranks print nothing there, whatever they do print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), cwd=os.getcwd()))
+    # rank 0's pipe is drained on a thread while the parent watches all ranks: when one of them fails the others would
+    # wait in a barrier for the group's timeout, so they get 30 s and are then ended (by their own PIDs)
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    reader.join(timeout=10.0)
+    sys.stdout.write(b"".join(out0).decode(errors="replace"))
+    sys.stdout.flush()
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        print("bench.py: rank return codes %s" % codes, file=sys.stderr)
+    raise SystemExit(min(worst, 255))
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d under a launcher with WORLD_SIZE=%s: start as many ranks as GPUs asked for"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
 
     import torch
     import torch.distributed as dist
@@ -160,16 +263,24 @@ def main():
     import accelerating_genomics_amd.synth as synth
 
     rank, local_rank, world = agd.env_rank()
-    multi = world > 1
-    if agx.device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible; libagx has no CPU fallback")
+    # a launcher (torch.distributed.run, or self_launch above) set WORLD_SIZE: the process group comes up even for one rank
+    multi = "WORLD_SIZE" in os.environ and ("MASTER_PORT" in os.environ)
+    n_dev = agx.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: rank %d of %d: no HIP device visible; libagx has no CPU fallback" % (rank, world))
+    masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
     if args.share_device:
         local_rank = 0
-    # a launcher that masks devices per rank (HIP_VISIBLE_DEVICES) leaves every rank one device, number 0
-    local_rank %= agx.device_count()
+    elif local_rank >= n_dev:
+        if masked and n_dev == 1:
+            local_rank = 0  # a launcher that masks devices per rank leaves every rank one device, number 0
+        else:
+            raise SystemExit("bench.py: rank %d wants device %d but only %d visible; a number measured with ranks sharing a GPU is not a "
+                             "%d-GPU number (--share-device rehearses the control flow)" % (rank, local_rank, n_dev, world))
     torch.cuda.set_device(local_rank)
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     cpu_group = None
+    control = {"backend": "none", "world_size": 1}
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # Gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE
@@ -185,13 +296,22 @@ def main():
             else:
                 dist.init_process_group("gloo")
                 dist.barrier()
+            # the three calls the run depends on, once, with values that can be checked
+            probe = torch.tensor([float(rank + 1)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+            rows = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
+            dist.all_gather(rows, torch.tensor([float(rank), float(local_rank)], dtype=torch.float64, device=red_dev))
+            assert float(probe.item()) == float(world) and [int(r[0].item()) for r in rows] == list(range(world)), "control plane self-check"
+            control = {"backend": args.dist_backend, "world_size": world, "tensors_on": red_dev,
+                       "self_check": "all_reduce(MAX) and all_gather returned the expected values",
+                       "devices_of_ranks": [int(r[1].item()) for r in rows], "self_launched": bool(os.environ.get("AGX_BENCH_SELF_LAUNCHED"))}
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     n_gpus = world if multi else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE %d; reporting n_gpus=%d" % (args.gpus, world, n_gpus), file=sys.stderr)
+    if args.gpus != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) are running" % (args.gpus, n_gpus))
 
     ctx = agx.Context(local_rank)
 
@@ -462,13 +582,38 @@ def main():
                                             max_rel_diff_to_bit_identical=c5m_rel, tolerance_asked=1e-12))
         out["multi_one_process"] = multi_one
         out["one_shot"] = one
+    # the figures of the other legs that a reader of the first few keys should not have to dig for
+    summ = {"int32_gcups": i32_leg["value"], "int32_ms_per_step": i32_leg["ms_per_step"], "int32_scores_identical_to_packed": i32_same,
+            "pairhmm_config3_f32_pairs_per_s": ph_leg["value"], "pairhmm_config3_ms_per_step": ph_leg["ms_per_step"]}
+    if extra:
+        summ.update({"config4_shard_gcups": out["config4"]["value"], "config4_total_gcups": out["config4"]["total"]["value"],
+                     "config4_total_n_shards": out["config4"]["total"]["n_shards"],
+                     "config5_shard_f64_pairs_per_s": out["config5"]["value"], "config5_total_f64_pairs_per_s": out["config5"]["total"]["value"],
+                     "multi_one_process_config4_ms": multi_one.get("config4", {}).get("ms"), "multi_one_process_config5_ms": multi_one.get("config5", {}).get("ms"),
+                     "one_shot_config2_pinned_ms_min": one["config2_pinned"]["ms_min"], "one_shot_config3_ms_min": one["config3_pageable"]["ms_min"]})
+    out["config"]["int32_gcups"], out["config"]["int32_ms_per_step"] = i32_leg["value"], i32_leg["ms_per_step"]
+    out["config"]["other_legs"] = summ
+    out["control_plane"] = control
     if not args.no_cpu_baseline and n_gpus == 1:  # the CPU baseline is reported at N=1 only
+        cores = host_cores()
+        n_par = max(1, min(cores, 64))
         out["cpu_baseline"] = _sw_ref_or_port(synth.sw_pairs(16384, SW_LEN, SW_LEN, seed=2, related_frac=0.25), "16384 of the 65536 config-2 pairs")
-        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        out["cpu_baseline"]["host_cores_available"] = cores
+        out["cpu_baseline"]["host_cores_of_the_machine"] = os.cpu_count()
         out["pairhmm"]["cpu_baseline"] = _phmm_ref_or_port(synth.phmm_regions(8, PH_READS, PH_HAPS, PH_R, PH_H, seed=3), "8192 of the 65536 config-3 pairs")
-        multi_cpu = cpu_baseline_sw_multicore(min(16, os.cpu_count() or 1), 4096)
+        out["pairhmm"]["cpu_baseline_antidiag"] = _phmm_ref_or_port(synth.phmm_regions(2, 16, 16, PH_R, PH_H, seed=3), "512 config-3-shaped pairs (2 regions of 16 reads x 16 haplotypes)",
+                                                                    program="phmm_antidiag_ref")
+        ph_multi = cpu_baseline_phmm_multicore(n_par, 2)
+        if ph_multi:
+            out["pairhmm"]["cpu_baseline_multicore"] = ph_multi
+        multi_cpu = cpu_baseline_sw_multicore(n_par, 4096)
         if multi_cpu:
             out["cpu_baseline_multicore"] = multi_cpu
+        # the driver's record keeps "cpu_baseline" whole: the other baselines are repeated inside it
+        out["cpu_baseline"]["pairhmm_config3"] = out["pairhmm"]["cpu_baseline"]
+        out["cpu_baseline"]["pairhmm_config3_antidiag"] = out["pairhmm"]["cpu_baseline_antidiag"]
+        out["cpu_baseline"]["pairhmm_config3_multicore"] = ph_multi
+        out["cpu_baseline"]["sw_multicore"] = multi_cpu
         if extra:
             out["config4"]["cpu_baseline"] = _sw_ref_or_port(synth.sw_pairs(4096, 32, 512, seed=4), "4096 config-4 pairs (lengths U[32,512])")
             out["config5"]["cpu_baseline"] = _phmm_ref_or_port(synth.phmm_regions(8, C5_READS, C5_HAPS, C5_R, C5_H, seed=5), "4096 config-5 pairs (R=250 H=500)")

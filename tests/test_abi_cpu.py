@@ -385,3 +385,32 @@ def test_shard_cut_rules_match_the_python_mirror():
         cut = agx.phmm_shard_cuts(p, shards)
         assert np.array_equal(cut.astype(np.int64), agd.shard_bounds(rb * hb, shards))
     assert list(agx.sw_shard_cuts(synth.sw_from_seqs([]), 4)) == [0, 0, 0, 0, 0]
+
+
+def test_one_shot_sw_read_of_a_file_beyond_64_mb(tmp_path):
+    """agx_sw_text_read made ONE reader call whose threaded branch read at most its 64 MB estimate and
+    returned rc 0 with fewer pairs than the file holds.  An 80 MB file through the one-shot call (several reader
+    threads: the pool has at least two) must come back whole; the chunked reader on the same file agrees."""
+    rng = np.random.default_rng(7)
+    n_lines = 200000
+    lens = rng.integers(300, 520, size=n_lines)
+    data = rng.integers(65, 91, size=int(lens.sum()) + n_lines, dtype=np.uint8)
+    ends = np.cumsum(lens + 1) - 1
+    data[ends] = 10
+    assert data.size > (72 << 20)
+    p = tmp_path / "big64.in"
+    with open(p, "wb") as f:
+        f.write(b"%d\n" % n_lines)
+        f.write(data.tobytes())
+    line_num, b, dang = agx.read_sw_text(str(p))
+    assert line_num == n_lines and b.n_pairs == n_lines // 2 and dang is None
+    assert np.array_equal(b.len.astype(np.int64), lens + 1)
+    starts = np.concatenate([[0], ends[:-1] + 1])
+    assert np.array_equal(b.off.astype(np.int64), starts)
+    for k in (0, 1, n_lines // 2 + 3, n_lines - 1):
+        assert b.bases[int(b.off[k]) : int(b.off[k]) + int(b.len[k])].tobytes() == data[starts[k] : ends[k] + 1].tobytes()
+    total = 0
+    for lnum, cb, d in agx.read_sw_text_chunks(str(p), 30000):
+        assert np.array_equal(cb.len.astype(np.int64), lens[2 * total : 2 * (total + cb.n_pairs)] + 1)
+        total += cb.n_pairs
+    assert total == n_lines // 2
