@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <functional>
+#include <thread>
 #include <vector>
 
 // Number of parts a parallel region may be split into (pool workers + the calling thread).
@@ -13,6 +14,35 @@ int agx_host_threads();
 // Runs task(part) for part = 0 .. parts-1; part 0 on the calling thread.  Reentrant from several
 // caller threads (device threads of the multi-device entry points share the pool).
 void agx_pool_run(int parts, const std::function<void(int)> &task);
+
+// A process that drives n devices at once lets the pool grow to 16 workers per device (at most the cores it may run on).
+void agx_pool_reserve(int n_devices);
+
+// One host thread per shard of a multi-device call, shard 0 on the caller.  shard(k) must not throw (the entry points
+// catch inside it).  When a thread cannot be started the shards without one run on the caller, after its own: the call
+// gets slower, it does not terminate with joinable threads behind it.
+template <typename F>
+void agx_fan_out(int n, F shard)
+{
+    if (n <= 1) {
+        if (n == 1) shard(0);
+        return;
+    }
+    agx_pool_reserve(n);
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+        th.reserve((size_t)n - 1);
+        for (int k = 1; k < n; ++k) {
+            th.emplace_back(shard, k);
+            started = k + 1;
+        }
+    } catch (...) {
+    }
+    shard(0);
+    for (int k = started; k < n; ++k) shard(k);
+    for (auto &t : th) t.join();
+}
 
 template <typename F>
 void agx_parallel_for(int64_t n, int64_t min_per_thread, F fn)

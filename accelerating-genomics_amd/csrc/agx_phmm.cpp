@@ -177,7 +177,9 @@ void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count,
 void build_lut(bool gatk_prior, double *d, float *f, double *mis_d, float *mis_f)
 {
     for (int c = 0; c < 256; ++c) {
-        d[c] = pow(10.0, -(c - 33.0) * 0.1);
+        // the reference holds the quality bytes in plain `char`, signed on x86-64 (:100-107): a byte of 0x80 and above
+        // is a negative number there (200 -> -56), and so it is here
+        d[c] = pow(10.0, -((c < 128 ? c : c - 256) - 33.0) * 0.1);
         f[c] = (float)d[c];
         mis_d[c] = gatk_prior ? d[c] / 3.0 : d[c];
         mis_f[c] = gatk_prior ? f[c] / 3.0f : f[c];
@@ -851,7 +853,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
             bool zero = false, other = false;
             for (int64_t r = ra; r < rz && !probs && precision != AGX_PHMM_F32; ++r)
                 for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k) {
-                    zero |= packed && d->q_gcp[k] <= (uint8_t)'!';
+                    zero |= packed && (int8_t)d->q_gcp[k] <= (int8_t)'!'; // signed as the reference's char: 0x80.. are "probabilities" above 1
                     other |= !(dna_table[d->read_bases[k]] & 1);
                 }
             if (zero || other) not_fast.store(true, std::memory_order_relaxed);
@@ -1433,14 +1435,7 @@ int agx_phmm_forward_devices(const int *devices, int n_devices, const agx_phmm_d
         if (r) errs[(size_t)k] = agx_last_error();
         rcs[(size_t)k] = r;
     };
-    if (n_devices == 1)
-        shard(0);
-    else {
-        std::vector<std::thread> th;
-        for (int k = 1; k < n_devices; ++k) th.emplace_back(shard, k);
-        shard(0);
-        for (auto &t : th) t.join();
-    }
+    agx_fan_out(n_devices, shard);
     for (int k = 0; k < n_devices; ++k)
         if (rcs[(size_t)k]) {
             agx_set_error("device %d: %s", devices[k], errs[(size_t)k].c_str());

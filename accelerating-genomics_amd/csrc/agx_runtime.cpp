@@ -1,5 +1,6 @@
 // Context, error text, stopwatch, buffer pools and the host thread pool of the C-ABI
 // (include/agx.h, "runtime" section).
+#include <sched.h>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -30,22 +31,50 @@ struct Pool {
     bool stop = false;
     int parts = 1;
 
+    static unsigned cores()
+    {
+        // the cores this process may run on (a GPU box gives one rank its share), not the machine's count
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) {
+            const int n = CPU_COUNT(&set);
+            if (n > 0) return (unsigned)n;
+        }
+        return std::max(1u, std::thread::hardware_concurrency());
+    }
     Pool()
     {
-        // At most 16 parts (a GPU box gives one rank 16 cores; counting sorts and the final log10 loop stop
-        // scaling about there), never more than half the machine so that 8 ranks do not oversubscribe it;
-        // AGX_HOST_THREADS (tuning build) overrides
+        // One planner splits its passes into at most 16 parts (counting sorts and the final log10 loop stop scaling
+        // about there), never more than an eighth of a large machine so that 8 ranks do not oversubscribe it;
+        // AGX_HOST_THREADS (tuning build) overrides.  The WORKERS behind the parts grow with the devices a process
+        // drives (reserve(): 16 per device, at most the cores), so that the planners of 8 device threads do not
+        // queue behind 15 workers.
         const char *e = agx_tune("AGX_HOST_THREADS");
         int n = e ? atoi(e) : 0;
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned hw = cores();
         if (n <= 0) n = (int)std::min(16u, std::max(hw >= 32 ? hw / 8 : hw, 1u));
         parts = n;
+        grow(n - 1);
+    }
+    void grow(int want_workers)
+    {
+        std::lock_guard<std::mutex> l(grow_mu);
         try {
-            for (int k = 0; k + 1 < n; ++k) workers.emplace_back([this] { loop(); });
+            while ((int)workers.size() < want_workers) workers.emplace_back([this] { loop(); });
         } catch (...) {
-            parts = (int)workers.size() + 1; // fewer threads than wanted is fine
+            if (workers.empty()) parts = 1; // fewer threads than wanted is fine; none at all: everything runs on the caller
         }
     }
+    void reserve(int n_devices)
+    {
+        if (agx_tune("AGX_HOST_THREADS")) return;
+        const int64_t want = std::min<int64_t>((int64_t)cores() - 1, (int64_t)parts * std::max(1, n_devices) - 1);
+        if (want > (int64_t)workers_hint.load(std::memory_order_relaxed)) {
+            grow((int)want);
+            workers_hint.store((int)want, std::memory_order_relaxed);
+        }
+    }
+    std::mutex grow_mu;
+    std::atomic<int> workers_hint{0};
     ~Pool()
     {
         {
@@ -94,6 +123,7 @@ Pool &pool()
 } // namespace
 
 int agx_host_threads() { return pool().parts; }
+void agx_pool_reserve(int n_devices) { pool().reserve(n_devices); }
 
 // the pool for the C readers (agx_text.c)
 extern "C" int agx_host_threads_c(void) { return agx_host_threads(); }
@@ -117,9 +147,13 @@ void agx_pool_run(int parts, const std::function<void(int)> &task)
     } sync;
     sync.left = parts - 1;
     {
-        std::lock_guard<std::mutex> l(p.mu);
+        // The jobs hold references to this frame (sync, task): they are built aside, where an allocation may fail with
+        // nothing queued yet, and enter the queue in ONE insertion at its end -- which either happens entirely or not at
+        // all (std::function moves do not throw) -- so no worker can hold a reference to a frame that is unwinding.
+        std::vector<std::function<void()>> mine_jobs;
+        mine_jobs.reserve((size_t)parts - 1);
         for (int t = 1; t < parts; ++t)
-            p.jobs.emplace_back([&sync, &task, t] {
+            mine_jobs.emplace_back([&sync, &task, t] {
                 std::exception_ptr e;
                 try {
                     task(t);
@@ -130,6 +164,8 @@ void agx_pool_run(int parts, const std::function<void(int)> &task)
                 if (e && !sync.err) sync.err = e;
                 if (--sync.left == 0) sync.cv.notify_one();
             });
+        std::lock_guard<std::mutex> l(p.mu);
+        p.jobs.insert(p.jobs.end(), std::make_move_iterator(mine_jobs.begin()), std::make_move_iterator(mine_jobs.end()));
         p.pending.fetch_add(parts - 1, std::memory_order_release);
     }
     p.cv.notify_all();

@@ -1241,14 +1241,7 @@ int agx_sw_score_devices(const int *devices, int n_devices, const uint8_t *bases
         if (r) errs[(size_t)k] = agx_last_error();
         rcs[(size_t)k] = r;
     };
-    if (n_devices == 1)
-        shard(0);
-    else {
-        std::vector<std::thread> th;
-        for (int k = 1; k < n_devices; ++k) th.emplace_back(shard, k);
-        shard(0);
-        for (auto &t : th) t.join();
-    }
+    agx_fan_out(n_devices, shard);
     for (int k = 0; k < n_devices; ++k)
         if (rcs[(size_t)k]) {
             agx_set_error("device %d: %s", devices[k], errs[(size_t)k].c_str());

@@ -812,8 +812,14 @@ int agx_phmm_reader_next(agx_phmm_reader *r, int64_t max_pairs, agx_phmm_text **
             head[hl] = 0;
             sscanf(head, "%d %d", &nr, &nh);
         }
-        if (nr < 0) nr = 0;
-        if (nh < 0) nh = 0;
+        if (nh < 0) {
+            /* :381-385: malloc(num_haplotypes * sizeof(char *)) of a negative count fails, the reference prints "Memory
+             * allocation failed for haplotypes array" and exits with failure after the `#batch:` line of this turn */
+            m->pub.truncated = 2;
+            r->finished = 1;
+            break;
+        }
+        if (nr < 0) nr = 0; /* a negative read count runs none of the reference's loops over reads */
         /* the reference reads the haplotypes first through a second stream (:389-407) and fails
          * with "Error reading haplotypes." when the region is cut short: nothing of it is output */
         int got_r = 0, got_h = 0;

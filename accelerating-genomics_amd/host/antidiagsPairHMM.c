@@ -158,7 +158,7 @@ int main(int argc, const char *argv[])
             pthread_join(warmer, NULL);
             warm_joined = 1;
         }
-        truncated |= t->truncated;
+        if (t->truncated) truncated = t->truncated;
         scored_chunk *c = (scored_chunk *)calloc(1, sizeof *c);
         double *lh = (double *)malloc(sizeof(double) * (size_t)(t->n_pairs ? t->n_pairs : 1));
         if (!c || !lh) {
@@ -194,7 +194,8 @@ int main(int argc, const char *argv[])
     if (status == EXIT_SUCCESS) {
         printf("#batch: %u\n", pr.batches + 1); /* the turn that meets EOF, or the truncated batch */
         if (truncated) {
-            fprintf(stderr, "Error reading haplotypes.\n"); /* :394-398 */
+            fprintf(stderr, truncated == 2 ? "Memory allocation failed for haplotypes array\n" /* :381-385, a negative count */
+                                           : "Error reading haplotypes.\n");                   /* :394-398 */
             status = EXIT_FAILURE;
         }
     }

@@ -302,7 +302,8 @@ typedef struct agx_phmm_text {
     agx_phmm_desc desc; /* points into storage owned by this object */
     int64_t n_pairs;
     int32_t n_regions_seen; /* header lines read, for the "#batch:" chatter */
-    int32_t truncated;      /* 1 = a region ended early (the reference exits with failure there) */
+    int32_t truncated;      /* 1 = a region ended early, 2 = a header with a negative haplotype count: the reference exits
+                             * with failure there ("Error reading haplotypes." / "Memory allocation failed for haplotypes array") */
 } agx_phmm_text;
 
 int agx_phmm_text_read(const char *path, agx_phmm_text **out);

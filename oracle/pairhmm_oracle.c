@@ -216,7 +216,8 @@ int oracle_pairhmm_batch(const unsigned char *rb, const unsigned char *qb, const
                          const uint32_t *hreg, int n_regions, double *out_sum, double *out_log10, int variant)
 {
     double lut[256];
-    for (int c = 0; c < 256; c++) lut[c] = oracle_phred_to_prob(c);
+    /* the reference holds quality bytes in plain `char`, signed on x86-64 (antidiagsPairHMM.c:99-107): byte 200 is -56 */
+    for (int c = 0; c < 256; c++) lut[c] = oracle_phred_to_prob((signed char)c);
     size_t k = 0;
     for (int g = 0; g < n_regions; g++) {
         for (uint32_t r = rreg[g]; r < rreg[g + 1]; r++) {

@@ -262,7 +262,10 @@ def _phmm_reference_reading_model(data: bytes):
             nr = int(m.group(1))
             if m.group(2) is not None:
                 nh = int(m.group(2))
-        nr, nh = max(nr, 0), max(nh, 0)
+        if nh < 0:          # :381-385: malloc of a negative count fails, "Memory allocation failed for haplotypes array"
+            truncated = 2
+            break
+        nr = max(nr, 0)     # a negative read count runs none of the loops over reads
         reads, haps = [], []
         while len(reads) < nr:
             line = fgets()
@@ -324,6 +327,7 @@ def _nasty_phmm_files():
     f["emptyline_header"] = region(1, 1, 20, 30) + b"\n" + readline(10) + b"\n" + seq(20, b"ACGT") + b"\n"
     f["zero_counts"] = b"0 2\nACGT\nACG\n" + region(1, 1, 10, 10) + b"2 0\n" + readline(5) + b"\n" + readline(6) + b"\n" + region(1, 1, 10, 10)
     f["negative"] = b"-1 2\nACGT\nACG\n" + region(1, 1, 10, 10)
+    f["negative_haps"] = region(2, 2, 10, 10) + b"2 -1\n" + region(1, 1, 10, 10)
     f["shortline"] = region(1, 1, 10, 10) + b"1 1\nAB\nACGT\n"
     f["shortfield"] = region(1, 1, 10, 10) + b"1 1\nACGTACGT II II II II\nACGT\n"
     f["empty"] = b""

@@ -153,6 +153,19 @@ def test_phmm_cli_streaming_truncated_batch(golden_dir, tmp_path):
     assert [l for l in r.stdout.splitlines() if l.startswith(b"#batch")] == [b"#batch: 1", b"#batch: 2"]
 
 
+def test_phmm_cli_negative_haplotype_count(golden_dir, tmp_path):
+    """a header with a negative haplotype count.  The compiled reference (run in the authoring container on
+    this very file: phmm_test.in, then `2 -1`, then phmm_test.in again) prints `#batch: 1`, the first value, `#batch: 2`,
+    "Memory allocation failed for haplotypes array" on stderr, writes the first value to the output file and exits 1
+    (antidiagsPairHMM.c:381-385)."""
+    data = open(os.path.join(golden_dir, "phmm_test.in"), "rb").read()
+    data += b"" if data.endswith(b"\n") else b"\n"
+    (tmp_path / "neg.in").write_bytes(data + b"2 -1\n" + data)
+    r = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), str(tmp_path / "neg.in"), str(tmp_path / "neg.out")], capture_output=True)
+    assert r.returncode == 1 and r.stderr == b"Memory allocation failed for haplotypes array\n"
+    assert r.stdout == b"#batch: 1\n-4.485565\n#batch: 2\n" and (tmp_path / "neg.out").read_bytes() == b"-4.485565\n"
+
+
 def test_sw_cli_config1_literal_fixture(golden_dir):
     """BASELINE config 1 as SURVEY 8d words it: the file `2\\n<a>\\n<b>\\n`, two iid 150-mers (seed 1); expected stdout
     from the compiled reference (tests/golden/make_golden.py)."""

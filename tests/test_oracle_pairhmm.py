@@ -58,3 +58,20 @@ def test_f32_underflows_on_unrelated_pairs(oracle, golden_dir):
     _, l64 = oracle.phmm_batch(b, 0)
     assert np.all(l64 < -90)
     assert np.all(s32 < 1e-30)  # denormal / zero in float
+
+
+def test_quality_bytes_above_0x7f_are_signed_chars(oracle, golden_dir):
+    """The reference holds quality bytes in plain `char` (signed on x86-64): phmm_hibit.in carries bytes >= 0x80 and its
+    %.17g output is the compiled pairHMMmatrix.c's.  Finite values bit for bit, NaN where the reference prints nan --
+    through the file front end (char arithmetic) and through the batch entry (byte arrays + LUT)."""
+    ref_txt = open(os.path.join(golden_dir, "phmm_hibit.g17.out")).read().split()
+    ref = np.array([float(x) for x in ref_txt])
+    fin = np.isfinite(ref)
+    assert 6 <= fin.sum() < ref.size
+    b = synth.parse_phmm_text(open(os.path.join(golden_dir, "phmm_hibit.in"), "rb").read())
+    for variant in (0, 1):
+        _, l = oracle.phmm_file(os.path.join(golden_dir, "phmm_hibit.in"), variant=variant)
+        assert np.array_equal(l[fin], ref[fin]) and np.array_equal(np.isnan(l), np.isnan(ref))
+        _, l = oracle.phmm_batch(b, variant)
+        assert np.array_equal(l[fin], ref[fin]) and np.array_equal(np.isnan(l), np.isnan(ref))
+    assert oracle.lib.oracle_phred_to_prob(200 - 256) == 10.0 ** 8.9 or abs(oracle.lib.oracle_phred_to_prob(200 - 256) / 10.0 ** 8.9 - 1) < 1e-15

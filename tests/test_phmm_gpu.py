@@ -40,6 +40,22 @@ def test_f64_bit_identical_to_reference_output(ctx, golden_dir, name):
     assert np.array_equal(got, ref)  # %.17g round-trips: every double equal
 
 
+def test_quality_bytes_above_0x7f_read_as_signed_char(ctx, golden_dir):
+    """the reference holds quality bytes in plain `char` (signed on x86-64, antidiagsPairHMM.c:99-107), so a
+    byte of 200 is Phred -89.  phmm_hibit.in has such bytes; its %.17g output comes from the compiled pairHMMmatrix.c.
+    Finite values bit for bit, the others (negative sums) NaN where the reference's are."""
+    b, _, _ = agx.read_phmm_text(os.path.join(golden_dir, "phmm_hibit.in"))
+    ref = g17(golden_dir, "phmm_hibit")
+    fin = np.isfinite(ref)
+    assert 6 <= fin.sum() < ref.size
+    got = ctx.phmm_forward(b, agx.PHMM_F64)
+    assert np.array_equal(got[fin], ref[fin]) and np.array_equal(np.isnan(got), np.isnan(ref))
+    for prec in (agx.PHMM_F64_FMA, agx.PHMM_F32, agx.PHMM_F32_FMA):  # garbage never crashes the other modes either
+        other = ctx.phmm_forward(b, prec)
+        clean = fin & (np.arange(ref.size) // 3 % 4 == 0)  # the reads without such a byte (first of every region)
+        assert relerr(other[clean], ref[clean]) <= (1e-12 if prec == agx.PHMM_F64_FMA else 1e-6)
+
+
 def test_reference_kat(ctx, golden_dir):
     b, _, _ = agx.read_phmm_text(os.path.join(golden_dir, "phmm_test.in"))
     assert "%f" % ctx.phmm_forward(b)[0] == open(os.path.join(golden_dir, "phmm_test.out")).read().strip() == "-4.485565"
