@@ -34,12 +34,21 @@ struct Pool {
     static unsigned cores()
     {
         // the cores this process may run on (a GPU box gives one rank its share), not the machine's count
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
         cpu_set_t set;
-        if (sched_getaffinity(0, sizeof set, &set) == 0) {
-            const int n = CPU_COUNT(&set);
-            if (n > 0) return (unsigned)n;
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+        // a container's CPU quota (cgroup v2 cpu.max "quota period"): the GPU boxes give a lease 16 cores per GPU of a
+        // 256-core host this way, with every core in the affinity mask
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long period = 0;
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+                const long quota = atol(q);
+                if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max(1L, (quota + period / 2) / period));
+            }
+            fclose(f);
         }
-        return std::max(1u, std::thread::hardware_concurrency());
+        return n;
     }
     Pool()
     {

@@ -169,11 +169,24 @@ def cpu_baseline_phmm_multicore(n_procs, regions_each):
 
 
 def host_cores():
-    """Cores this process may run on (the box's share), not the machine's count."""
+    """Cores this process may use (the box's share): its affinity mask, cut by the cgroup's CPU quota where one is set."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())      # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def parse_args(argv=None):
@@ -302,6 +315,18 @@ def main():
             rows = [torch.zeros(2, dtype=torch.float64, device=red_dev) for _ in range(world)]
             dist.all_gather(rows, torch.tensor([float(rank), float(local_rank)], dtype=torch.float64, device=red_dev))
             assert float(probe.item()) == float(world) and [int(r[0].item()) for r in rows] == list(range(world)), "control plane self-check"
+            # two ranks on one GPU would report a number that is not an N-GPU number: every rank names the device it took
+            # (the masks that hide devices from it, the ordinal inside them, the device's UUID where torch tells it)
+            try:
+                uuid = str(torch.cuda.get_device_properties(local_rank).uuid)
+            except Exception:
+                uuid = ""
+            me = (os.uname().nodename, tuple(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")), local_rank, uuid)
+            names = [None] * world
+            dist.all_gather_object(names, me, group=cpu_group)
+            if len(set(names)) < world and not args.share_device:
+                raise SystemExit("bench.py: rank %d: ranks share a GPU (%s); a number measured that way is not a %d-GPU number "
+                                 "(--share-device rehearses the control flow)" % (rank, names, world))
             control = {"backend": args.dist_backend, "world_size": world, "tensors_on": red_dev,
                        "self_check": "all_reduce(MAX) and all_gather returned the expected values",
                        "devices_of_ranks": [int(r[1].item()) for r in rows], "self_launched": bool(os.environ.get("AGX_BENCH_SELF_LAUNCHED"))}

@@ -59,4 +59,4 @@ def test_ranks_that_would_share_a_gpu_are_refused_without_the_rehearsal_flag():
     if n_dev >= 2:
         assert r.returncode == 0
     else:
-        assert r.returncode != 0 and "is not a 2-GPU number" in r.stderr and r.stdout.strip() == ""
+        assert r.returncode != 0 and "is not a 2-GPU number" in r.stderr and r.stdout.strip() == "", r.stderr[-2000:]
