@@ -19,6 +19,8 @@ LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, _DEFAULT_LIB))  # 
 
 OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_SYMBOL, E_LIMIT, E_IO = 0, -1, -2, -3, -4, -5, -6, -7
 OPT_SW_KERNEL = 1
+OPT_SW_PLANNER = 2
+SW_PLANNER_AUTO, SW_PLANNER_HOST, SW_PLANNER_DEVICE = 0, 1, 2
 SW_KERNEL_AUTO, SW_KERNEL_INT32, SW_KERNEL_PACKED_SIGNED, SW_KERNEL_PACKED_BIASED = 0, 1, 2, 3
 PHMM_F64, PHMM_F64_FMA, PHMM_F32, PHMM_F32_FMA = 0, 1, 2, 3
 PHMM_GATK_PRIOR = 0x100  # OR-able into the precision
@@ -47,7 +49,7 @@ class AgxError(RuntimeError):
 
 class SwInfo(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("cells", C.c_int64), ("padded_cells", C.c_int64), ("input_bytes", C.c_int64),
-                ("n_launches", C.c_int32), ("n_waves", C.c_int32)]
+                ("n_launches", C.c_int32), ("n_waves", C.c_int32), ("planned_on_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SwScoring(C.Structure):

@@ -83,11 +83,19 @@ struct agx_ctx {
     std::mutex pool_mu;
     std::vector<PoolBlock> free_dev, free_pin;
     size_t cached_dev = 0, cached_pin = 0;
+    // Device-side planning (agx_sw_plan_kernel.hip): its own stream, so that the planning kernels run beside the
+    // upload of the sequences on `copy`, an event the pack kernel waits for, and the tiling table of the packed
+    // biased fill on the device (made on first use, freed with the context).
+    hipStream_t plan = nullptr;
+    hipEvent_t plan_done = nullptr;
+    void *sw_seg_first = nullptr, *sw_segs = nullptr;
     // options (agx_ctx_set_option)
     int opt_sw_kernel = 0;
+    int opt_sw_planner = 0;
 };
 
 int agx_ctx_prepare_fanout(agx_ctx *c); // side streams + events for batches of several launches
+int agx_ctx_prepare_plan(agx_ctx *c);   // the planning stream and its event
 void agx_ctx_retain(agx_ctx *c);
 void agx_ctx_release(agx_ctx *c); // frees everything when the last reference goes
 

@@ -384,6 +384,14 @@ int agx_ctx_prepare_fanout(agx_ctx *c)
     return AGX_OK;
 }
 
+int agx_ctx_prepare_plan(agx_ctx *c)
+{
+    if (c->plan) return AGX_OK;
+    AGX_HIP(hipStreamCreateWithFlags(&c->plan, hipStreamNonBlocking));
+    AGX_HIP(hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming));
+    return AGX_OK;
+}
+
 hipStream_t FanOut::stream(int k)
 {
     if (n <= 1) return c->stream;
@@ -429,6 +437,10 @@ void agx_ctx_release(agx_ctx *c)
         if (c->aux[k]) (void)hipStreamDestroy(c->aux[k]);
     }
     if (c->copy) (void)hipStreamDestroy(c->copy);
+    if (c->plan) (void)hipStreamDestroy(c->plan);
+    if (c->plan_done) (void)hipEventDestroy(c->plan_done);
+    if (c->sw_seg_first) (void)hipFree(c->sw_seg_first);
+    if (c->sw_segs) (void)hipFree(c->sw_segs);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -585,6 +597,10 @@ int agx_ctx_set_option(agx_ctx *c, int key, int64_t value)
     case AGX_OPT_SW_KERNEL:
         if (value < AGX_SW_KERNEL_AUTO || value > AGX_SW_KERNEL_PACKED_BIASED) break;
         c->opt_sw_kernel = (int)value;
+        return AGX_OK;
+    case AGX_OPT_SW_PLANNER:
+        if (value < AGX_SW_PLANNER_AUTO || value > AGX_SW_PLANNER_DEVICE) break;
+        c->opt_sw_planner = (int)value;
         return AGX_OK;
     default: break;
     }

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <thread>
 
@@ -202,6 +203,7 @@ Tiling choose_tiling_uniform(const double *costs, int slots, int lx, int ly, int
     return best;
 }
 
+constexpr size_t kRawPad = 64;       // bytes in front of and behind the uploaded sequences (16-byte aligned pieces, agx_sw_pack_kernel.hip)
 constexpr uint8_t kClsEmpty = 255;   // an empty side: nothing to fill
 constexpr uint8_t kClsUntiled = 254; // pass A done, no tiling yet
 struct PairPlan {                    // 12 bytes: the sorts move these
@@ -300,6 +302,123 @@ int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const 
 
 namespace {
 
+// Batches of at least this many pairs are candidates for the device planner: below it the host's threaded passes
+// take well under a millisecond and the batch is in the tail regime anyway.
+constexpr int64_t kDevPlanMinPairs = 49152;
+
+// The full tiling table of a kernel family (every class allowed, no tail term, every shorter length up to the
+// family's limit): what a device-planned batch is tiled with.  Made once per process.
+const TilingTable &full_tiling_table(int family)
+{
+    static TilingTable tabs[3];
+    static std::once_flag once[3];
+    std::call_once(once[family], [family] {
+        const std::vector<uint8_t> present((size_t)(family == 0 ? AGX_SW_MAX_SHORT_LEN : kSwPackedMaxShort) + 1, 1);
+        build_tiling_table(tabs[family], present, class_costs(family), ~0u, 0.0);
+    });
+    return tabs[family];
+}
+
+// temporaries of a device-planned batch (released when create_batch leaves)
+struct DevPlan {
+    PinBuf h_len, h_buckets, h_padded;
+    DevBuf d_len, d_buckets, d_padded, keys_a, keys_b, vals_a, vals_b, wkeys_a, wkeys_b, wids_a, wids_b, waves_tmp, temp;
+    std::vector<uint32_t> hist; // pairs per (class, G) bucket
+    size_t img_dw = 0;
+    bool started = false;
+    void release()
+    {
+        for (PinBuf *x : {&h_len, &h_buckets, &h_padded}) x->release();
+        for (DevBuf *x : {&d_len, &d_buckets, &d_padded, &keys_a, &keys_b, &vals_a, &vals_b, &wkeys_a, &wkeys_b, &wids_a, &wids_b, &waves_tmp, &temp})
+            x->release();
+    }
+};
+
+// the family-2 tiling table on the device, made on the context's first device-planned batch
+int ensure_device_table(agx_ctx *ctx, hipStream_t s)
+{
+    if (ctx->sw_seg_first) return AGX_OK;
+    const TilingTable &tt = full_tiling_table(2);
+    std::vector<uint32_t> segs(tt.segs.size());
+    for (size_t k = 0; k < segs.size(); ++k) segs[k] = (tt.segs[k].ly_from & 0xffffu) | ((uint32_t)tt.segs[k].cls << 16) | ((uint32_t)tt.segs[k].G << 24);
+    void *d_first = nullptr, *d_segs = nullptr;
+    AGX_HIP(hipMalloc(&d_first, tt.first.size() * sizeof(uint32_t)));
+    if (hipMalloc(&d_segs, std::max<size_t>(segs.size(), 1) * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(d_first);
+        agx_set_error("device tiling table: out of device memory");
+        return AGX_E_NOMEM;
+    }
+    // (pageable sources: these two copies return when the data has left the host buffers)
+    hipError_t e = hipMemcpyAsync(d_first, tt.first.data(), tt.first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && !segs.empty()) e = hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        (void)hipFree(d_first);
+        (void)hipFree(d_segs);
+        agx_set_error("device tiling table: upload -> %s", hipGetErrorString(e));
+        return AGX_E_HIP;
+    }
+    ctx->sw_seg_first = d_first;
+    ctx->sw_segs = d_segs;
+    return AGX_OK;
+}
+
+// Allocates the batch's record arrays and the planner's temporaries, uploads len[] and the bucket table and queues the
+// planning kernels on the context's planning stream; ctx->plan_done is recorded behind them.
+int launch_device_plan(agx_ctx *ctx, DevPlan &dp, agx_sw_batch *b, uint32_t n_pairs, uint32_t n_fill, uint32_t longest_long, int slots, uint32_t img0,
+                       size_t n_groups, size_t n_waves)
+{
+    hipStream_t ps = ctx->plan;
+    agx_sw_plan_preload();
+    int rc = ensure_device_table(ctx, ps);
+    const size_t pw = (size_t)n_pairs * sizeof(uint32_t), ww = std::max<size_t>(n_waves, 1) * sizeof(uint32_t);
+    const size_t temp_bytes = agx_sw_plan_temp_bytes(n_pairs, (uint32_t)n_waves);
+    if (!rc) rc = b->groups.alloc(ctx, std::max<size_t>(n_groups, 1) * sizeof(SwGroup2));
+    if (!rc) rc = b->waves.alloc(ctx, std::max<size_t>(n_waves, 1) * sizeof(SwWave));
+    if (!rc) rc = dp.d_len.alloc(ctx, 2 * pw);
+    if (!rc) rc = dp.d_buckets.alloc(ctx, dp.h_buckets.bytes);
+    if (!rc) rc = dp.d_padded.alloc(ctx, 64);
+    if (!rc) rc = dp.h_padded.alloc(ctx, 64);
+    for (DevBuf *x : {&dp.keys_a, &dp.keys_b, &dp.vals_a, &dp.vals_b})
+        if (!rc) rc = x->alloc(ctx, pw);
+    for (DevBuf *x : {&dp.wkeys_a, &dp.wkeys_b, &dp.wids_a, &dp.wids_b})
+        if (!rc) rc = x->alloc(ctx, ww);
+    if (!rc) rc = dp.waves_tmp.alloc(ctx, std::max<size_t>(n_waves, 1) * sizeof(SwWave));
+    if (!rc) rc = dp.temp.alloc(ctx, temp_bytes);
+    if (rc) return rc;
+    dp.started = true;
+    AGX_HIP(hipMemcpyAsync(dp.d_len.p, dp.h_len.p, 2 * pw, hipMemcpyHostToDevice, ps));
+    AGX_HIP(hipMemcpyAsync(dp.d_buckets.p, dp.h_buckets.p, dp.h_buckets.bytes, hipMemcpyHostToDevice, ps));
+    AGX_HIP(hipMemsetAsync(dp.d_padded.p, 0, 8, ps));
+    SwPlanArgs a{};
+    a.len = (const uint32_t *)dp.d_len.p;
+    a.n_pairs = n_pairs;
+    a.n_fill = n_fill;
+    a.seg_first = (const uint32_t *)ctx->sw_seg_first;
+    a.segs = (const uint32_t *)ctx->sw_segs;
+    a.longest = longest_long;
+    a.buckets = (const uint32_t *)dp.d_buckets.p;
+    a.img0 = img0;
+    a.slots = slots;
+    a.n_waves = (uint32_t)n_waves;
+    a.keys_a = (uint32_t *)dp.keys_a.p, a.keys_b = (uint32_t *)dp.keys_b.p, a.vals_a = (uint32_t *)dp.vals_a.p, a.vals_b = (uint32_t *)dp.vals_b.p;
+    a.wave_keys_a = (uint32_t *)dp.wkeys_a.p, a.wave_keys_b = (uint32_t *)dp.wkeys_b.p, a.wave_ids_a = (uint32_t *)dp.wids_a.p, a.wave_ids_b = (uint32_t *)dp.wids_b.p;
+    a.waves_tmp = (SwWave *)dp.waves_tmp.p;
+    a.waves = (SwWave *)b->waves.p;
+    a.groups = (uint32_t *)b->groups.p;
+    a.padded = (unsigned long long *)dp.d_padded.p;
+    a.temp = dp.temp.p;
+    a.temp_bytes = temp_bytes;
+    a.n_cu = ctx->n_cu;
+    if (agx_sw_plan_launch(a, ps)) {
+        agx_set_error("device planner: launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return AGX_E_HIP;
+    }
+    AGX_HIP(hipMemcpyAsync(dp.h_padded.p, dp.d_padded.p, 8, hipMemcpyDeviceToHost, ps));
+    AGX_HIP(hipEventRecord(ctx->plan_done, ps));
+    return AGX_OK;
+}
+
 int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matrix *matrix, const uint8_t *bases,
                  const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
 {
@@ -387,8 +506,22 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             }
     }
 
+    // ---- where the per-pair passes of the planner will run.  A large batch for the packed biased fill is a candidate
+    // for the device planner (agx_sw_plan_kernel.hip): pass A then only reduces -- no per-pair record is written on the
+    // host -- and the batch-level rules decide below whether the candidate stands (a uniform batch, one in the tail
+    // regime or with a dominant shape is planned on the host as before).
+    const int want = tuned_kernel() ? tuned_kernel() : ctx ? ctx->opt_sw_kernel : AGX_SW_KERNEL_AUTO;
+    const int planner_opt = ctx ? ctx->opt_sw_planner : AGX_SW_PLANNER_HOST;
+    bool dev_candidate = ctx && !matrix && planner_opt != AGX_SW_PLANNER_HOST && n_pairs > 0 &&
+                         (planner_opt == AGX_SW_PLANNER_DEVICE || n_pairs >= kDevPlanMinPairs) &&
+                         (want == AGX_SW_KERNEL_AUTO || want == AGX_SW_KERNEL_PACKED_BIASED) && tail_beta_override() < 0 &&
+                         !max_classes_override() && !agx_tune("AGX_SW_SORT_WAVES") && !agx_tune("AGX_SW_ONE_LAUNCH") &&
+                         !agx_tune("AGX_SW_WAVES_PER_CLASS") && !agx_tune("AGX_SW_HOST_PLAN");
+
     // ---- pass A (threads over pairs): orient, check the limits, count cells, extent of `bases`
-    std::vector<PairPlan> all((size_t)n_pairs);
+    std::vector<PairPlan> all;
+    if (!dev_candidate) all.resize((size_t)n_pairs);
+    PairPlan *allp = dev_candidate ? nullptr : all.data();
     const uint32_t hard_max_short = matrix ? (uint32_t)kSwPackedMaxShort : AGX_SW_MAX_SHORT_LEN; // no wide classes in matrix mode
     struct Worker {
         int rc = AGX_OK;
@@ -408,7 +541,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         Worker &me = wk[(size_t)tid];
         me.present.assign((size_t)hard_max_short + 1, 0);
         for (int64_t p = lo; p < hi; ++p) {
-            PairPlan &pp = all[(size_t)p];
+            PairPlan scratch;
+            PairPlan &pp = allp ? allp[(size_t)p] : scratch;
             pp = PairPlan{};
             pp.pair = (uint32_t)p;
             pp.cls = kClsEmpty;
@@ -473,7 +607,6 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     // pair moves the whole batch to the int32 kernel, which also has the wide classes (up to 64 x 160).
     // Biased formulation: every stored half must be the pattern of a positive normal half-precision number,
     // [0x0400, 0x7c00): smallest B - max(|gf| + |ge|, delta), largest B + (longest shorter side + 1) * match + |gf|.
-    const int want = tuned_kernel() ? tuned_kernel() : ctx ? ctx->opt_sw_kernel : AGX_SW_KERNEL_AUTO;
     int family = want == AGX_SW_KERNEL_INT32 ? 0 : want == AGX_SW_KERNEL_PACKED_SIGNED ? 1 : 2;
     if (matrix || longest_short > (uint32_t)kSwPackedMaxShort) family = 0; // the matrix lookup exists in the int32 kernel only
     if (family == 2 && !((int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00)) family = 1;
@@ -565,7 +698,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                 snprintf(up_err, sizeof up_err, "hipSetDevice failed on the upload thread");
                 return;
             }
-            int r = d_raw.alloc(ctx, (size_t)raw_bytes + 64);
+            int r = d_raw.alloc(ctx, (size_t)raw_bytes + 2 * kRawPad); // the pack kernels read 16-byte pieces that may begin before / end behind the sequences
             if (!r) r = d_off.alloc(ctx, (size_t)n_pairs * 2 * sizeof(uint64_t));
             if (!r) r = d_flag.alloc(ctx, 2 * sizeof(uint32_t));
             if (!r && matrix) r = d_code.alloc(ctx, 256);
@@ -617,7 +750,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                         const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
                         if (lo < hi) memcpy((uint8_t *)ring[slot].p + lo, src + at + lo, hi - lo);
                     });
-                    if (!r && (hipMemcpyAsync((uint8_t *)d_raw.p + at, ring[slot].p, n, hipMemcpyHostToDevice, ctx->copy) != hipSuccess ||
+                    if (!r && (hipMemcpyAsync((uint8_t *)d_raw.p + kRawPad + at, ring[slot].p, n, hipMemcpyHostToDevice, ctx->copy) != hipSuccess ||
                                hipEventRecord(done[slot], ctx->copy) != hipSuccess))
                         r = AGX_E_HIP;
                 }
@@ -630,7 +763,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                 }
                 if (r) e = hipErrorUnknown;
             } else if (raw_bytes)
-                e = hipMemcpyAsync(d_raw.p, src, (size_t)raw_bytes, hipMemcpyHostToDevice, ctx->copy);
+                e = hipMemcpyAsync((uint8_t *)d_raw.p + kRawPad, src, (size_t)raw_bytes, hipMemcpyHostToDevice, ctx->copy);
             if (e == hipSuccess)
                 e = hipMemcpyAsync(d_off.p, src_off, (size_t)n_pairs * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->copy);
             if (e == hipSuccess && matrix) e = hipMemcpyAsync(d_code.p, matrix->code, 256, hipMemcpyHostToDevice, ctx->copy);
@@ -655,41 +788,148 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     } joiner{uploader};
     if (ctx && n_pairs > 0) uploader = std::thread(upload_inputs);
 
+    // one shape in the whole batch?
+    int64_t n_fill = 0;
+    uint32_t shape = 0xffffffffu;
+    bool one_shape = true;
+    for (const Worker &w : wk) {
+        n_fill += w.n_fill;
+        if (w.mixed) one_shape = false;
+        if (w.shape0 != 0xffffffffu) {
+            if (shape == 0xffffffffu) shape = w.shape0;
+            else if (shape != w.shape0) one_shape = false;
+        }
+    }
+    const bool uniform = one_shape && n_fill == n_pairs && n_pairs >= 1024 && n_cu > 0;
+
+    // ---- device planner: the candidate's verdict.  Pass A2 (threads over pairs) tiles every pair by lookup in the
+    // full table and only COUNTS: pairs per (class, G) bucket -- from which every group, wave and record offset
+    // follows without a scan -- image words, estimated waves, the votes of the sampled dominant shape; it also
+    // copies len[] into page-locked memory for its upload.  The rules that need another tiling (tail regime,
+    // class consolidation, dominant shape) send the batch to the host planner.
+    bool device_plan = false;
+    DevPlan dp;
+    struct DevPlanGuard { // kernels may still read the temporaries when an error path leaves
+        agx_ctx *c;
+        DevPlan &d;
+        ~DevPlanGuard()
+        {
+            if (d.started && c && c->plan) (void)hipStreamSynchronize(c->plan);
+            d.release();
+        }
+    } dp_guard{ctx, dp};
+    if (dev_candidate && family == 2 && !uniform && n_cu > 0 && n_fill > 0 && longest_short <= (uint32_t)kSwPackedMaxShort) {
+        const TilingTable &tt = full_tiling_table(family);
+        rc = dp.h_len.alloc(ctx, (size_t)n_pairs * 2 * sizeof(uint32_t));
+        if (rc) return rc;
+        uint32_t cand = 0;
+        int votes = 0;
+        {
+            const size_t stride = std::max<size_t>(1, (size_t)n_pairs / 512);
+            for (size_t k = 0; k < 512 && k * stride < (size_t)n_pairs; ++k) { // Boyer-Moore majority vote over a sample
+                const uint32_t la = len[2 * k * stride], lb = len[2 * k * stride + 1];
+                if (la == 0 || lb == 0) continue;
+                const uint32_t sh = std::min(la, lb) << 16 | (std::max(la, lb) & 0xffffu);
+                if (votes == 0) {
+                    cand = sh;
+                    votes = 1;
+                } else
+                    votes += sh == cand ? 1 : -1;
+            }
+        }
+        struct Count {
+            std::vector<uint32_t> hist;
+            uint64_t words = 0;
+            double waves = 0;
+            int64_t votes = 0;
+            bool untiled = false;
+        };
+        std::vector<Count> cnt((size_t)agx_host_threads());
+        uint32_t *pinned_len = (uint32_t *)dp.h_len.p;
+        agx_parallel_for(n_pairs, 8192, [&](int64_t lo, int64_t hi, int tid) {
+            Count &me = cnt[(size_t)tid];
+            me.hist.assign((size_t)kSwPlanBuckets, 0);
+            memcpy(pinned_len + 2 * lo, len + 2 * lo, (size_t)(hi - lo) * 2 * sizeof(uint32_t));
+            for (int64_t p = lo; p < hi; ++p) {
+                const uint32_t la = len[2 * p], lb = len[2 * p + 1];
+                if (la == 0 || lb == 0) continue;
+                const uint32_t lx = std::min(la, lb), ly = std::max(la, lb);
+                Tiling tl;
+                if (!tt.pick(lx, ly, &tl, nullptr)) {
+                    me.untiled = true;
+                    continue;
+                }
+                ++me.hist[(size_t)tl.cls * 64 + (size_t)(64 - tl.G)];
+                me.words += ((uint64_t)tl.G * kSwClasses[tl.cls] + 3) / 4 + 1 + ((uint64_t)ly + 3) / 4;
+                me.waves += (double)tl.G / 64.0 / slots;
+                me.votes += (lx << 16 | (ly & 0xffffu)) == cand;
+            }
+        });
+        dp.hist.assign((size_t)kSwPlanBuckets, 0);
+        uint64_t words = 0;
+        double waves_est = 0;
+        int64_t cand_count = 0;
+        bool untiled = false;
+        for (const Count &c : cnt) {
+            if (c.hist.empty()) continue;
+            for (int k = 0; k < kSwPlanBuckets; ++k) dp.hist[(size_t)k] += c.hist[(size_t)k];
+            words += c.words;
+            waves_est += c.waves;
+            cand_count += c.votes;
+            untiled |= c.untiled;
+        }
+        const double fill = waves_est / (5.0 * 4.0 * n_cu);
+        const size_t img_dw_dev = (size_t)kSwPackedMaxShort / 4 + 1 + words;
+        device_plan = !untiled && fill >= 0.48 && waves_est >= 2048.0 && !(votes > 0 && cand_count * 2 >= n_pairs) && img_dw_dev <= 0xffffffffull;
+        dp.img_dw = img_dw_dev;
+        if (trace)
+            fprintf(stderr, "[agx_sw_batch_create] device planner verdict %d: untiled %d, waves %.0f (fill %.2f), sampled shape votes %d -> %lld of %lld pairs, image %zu words\n",
+                    (int)device_plan, (int)untiled, waves_est, fill, votes, (long long)cand_count, (long long)n_pairs, img_dw_dev);
+    } else if (trace)
+        fprintf(stderr, "[agx_sw_batch_create] no device planner: candidate %d, family %d, uniform %d, n_fill %lld, longest shorter side %u\n",
+                (int)dev_candidate, family, (int)uniform, (long long)n_fill, longest_short);
+    if (dev_candidate && !device_plan) { // the host planner after all: its per-pair records, as pass A would have written them
+        all.resize((size_t)n_pairs);
+        allp = all.data();
+        agx_parallel_for(n_pairs, 8192, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t p = lo; p < hi; ++p) {
+                PairPlan &pp = allp[(size_t)p];
+                pp = PairPlan{};
+                pp.pair = (uint32_t)p;
+                pp.cls = kClsEmpty;
+                const uint32_t la = len[2 * p], lb = len[2 * p + 1];
+                if (la == 0 || lb == 0) continue;
+                const bool second_short = lb < la;
+                pp.lxo = (uint16_t)((second_short ? lb : la) | (second_short ? 0x8000u : 0u));
+                pp.ly = second_short ? la : lb;
+                pp.cls = kClsUntiled;
+            }
+        });
+        dp.h_len.release();
+    }
+
     // ---- uniform batches (fixed-length reads: BASELINE config 2): one shape, so one tiling -- chosen with the
     // wave-count quantisation below -- and nothing to sort: file order is already the order passes B and C
     // would produce.
     std::vector<PairPlan> plan;
     bool planned = false;
-    {
-        int64_t n_fill = 0;
-        uint32_t shape = 0xffffffffu;
-        bool one_shape = true;
-        for (const Worker &w : wk) {
-            n_fill += w.n_fill;
-            if (w.mixed) one_shape = false;
-            if (w.shape0 != 0xffffffffu) {
-                if (shape == 0xffffffffu) shape = w.shape0;
-                else if (shape != w.shape0) one_shape = false;
-            }
-        }
-        if (one_shape && n_fill == n_pairs && n_pairs >= 1024 && n_cu > 0) {
-            const Tiling tl = choose_tiling_uniform(costs, slots, (int)(shape >> 16), (int)(shape & 0xffffu), n_pairs, 4 * n_cu);
-            if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
-                agx_parallel_for(n_pairs, 32768, [&](int64_t lo, int64_t hi, int) {
-                    for (int64_t p = lo; p < hi; ++p) {
-                        all[(size_t)p].cls = (uint8_t)tl.cls;
-                        all[(size_t)p].G = (uint8_t)tl.G;
-                    }
-                });
-                plan.swap(all);
-                planned = true;
-            }
+    if (uniform) {
+        const Tiling tl = choose_tiling_uniform(costs, slots, (int)(shape >> 16), (int)(shape & 0xffffu), n_pairs, 4 * n_cu);
+        if (tl.cls >= 0 && !(matrix && kSwClasses[tl.cls] > 40)) {
+            agx_parallel_for(n_pairs, 32768, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t p = lo; p < hi; ++p) {
+                    all[(size_t)p].cls = (uint8_t)tl.cls;
+                    all[(size_t)p].G = (uint8_t)tl.G;
+                }
+            });
+            plan.swap(all);
+            planned = true;
         }
     }
     double t_plan = now_ms(), t_sort = t_plan;
 
     // ---- pass B: lane tiling per pair, then the batch-level rules.  Host-only work from here to the records.
-    if (!planned) {
+    if (!planned && !device_plan) {
     TilingTable tt;
     double beta_used = tail_beta_override() >= 0 ? tail_beta_override() : 0.0;
     auto tile_all = [&](uint32_t allowed, double beta, bool only_outside) {
@@ -839,8 +1079,54 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         while (!plan.empty() && plan.back().cls == kClsEmpty) plan.pop_back();
     }
     t_sort = now_ms();
-    } // !planned
+    } // !planned && !device_plan
 
+    // what the rest of the function needs of a plan, whoever made it
+    size_t n_groups = 0, n_waves_total = 0, groups_bytes = 0, waves_bytes = 0;
+    const size_t img0 = packed ? (size_t)kSwPackedMaxShort / 4 + 1 : 0;
+    size_t img_dw = img0;
+    std::vector<SwWave> waves;
+    std::vector<ClassLaunch> launches;
+    int64_t padded = 0;
+    double t_waves = t_sort, t_records = t_sort;
+    std::vector<uint8_t> groups_host; // plan-only: no pinned memory without a device
+    if (device_plan) {
+        // ---- the buckets' extents from their counts (ascending bucket id = the sort order), then everything per pair on
+        // the device, on the planning stream, beside the upload of the sequences
+        rc = agx_ctx_prepare_plan(ctx);
+        if (!rc) rc = dp.h_buckets.alloc(ctx, (size_t)kSwPlanBuckets * 5 * sizeof(uint32_t));
+        if (rc) return rc;
+        uint32_t *bt = (uint32_t *)dp.h_buckets.p;
+        size_t entries = 0, n_waves = 0;
+        uint32_t class_mask = 0;
+        for (int k = 0; k < kSwPlanBuckets; ++k) {
+            const size_t count = dp.hist[(size_t)k];
+            const int G = 64 - (k & 63);
+            const size_t ng = (count + slots - 1) / slots, per_wave = (size_t)(64 / G), nw = (ng + per_wave - 1) / per_wave;
+            bt[5 * k + 0] = (uint32_t)entries;
+            bt[5 * k + 1] = (uint32_t)count;
+            bt[5 * k + 2] = (uint32_t)n_groups;
+            bt[5 * k + 3] = (uint32_t)ng;
+            bt[5 * k + 4] = (uint32_t)n_waves;
+            entries += count;
+            n_groups += ng;
+            n_waves += nw;
+            if (count) class_mask |= 1u << (k >> 6);
+        }
+        n_waves_total = n_waves;
+        img_dw = dp.img_dw;
+        groups_bytes = n_groups * sizeof(SwGroup2);
+        waves_bytes = n_waves * sizeof(SwWave);
+        ClassLaunch cl; // several classes: ONE launch, the class read per wave (sw_fill_pk2_any); else that class's own fill
+        cl.C = (class_mask & (class_mask - 1)) ? 0 : kSwClasses[__builtin_ctz(class_mask)];
+        cl.first_wave = 0;
+        cl.n_waves = (uint32_t)n_waves;
+        launches.assign(1, cl);
+        rc = launch_device_plan(ctx, dp, b, (uint32_t)n_pairs, (uint32_t)entries, longest_long, slots, (uint32_t)img0, n_groups, n_waves);
+        if (!rc) rc = h_flag.alloc(ctx, 2 * sizeof(uint32_t));
+        if (rc) return rc;
+        t_waves = t_records = now_ms();
+    } else {
     // ---- pass D: every (class, G) bucket is regular, so waves, records and offsets need no scan but the
     // prefix sum of the image words.
     std::vector<Bucket> bk;
@@ -859,7 +1145,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         i = lo + 1;
         bk.push_back(q);
     }
-    size_t n_groups = 0, n_waves = 0;
+    size_t n_waves = 0;
     for (Bucket &q : bk) {
         q.group0 = n_groups;
         q.n_groups = (q.count + slots - 1) / slots;
@@ -869,9 +1155,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         q.n_waves = (q.n_groups + per_wave - 1) / per_wave;
         n_waves += q.n_waves;
     }
-    std::vector<SwWave> waves(n_waves);
-    std::vector<ClassLaunch> launches;
-    int64_t padded = 0;
+    waves.assign(n_waves, SwWave{});
     for (const Bucket &q : bk) {
         if (launches.empty() || launches.back().C != kSwClasses[q.cls]) {
             ClassLaunch cl;
@@ -922,8 +1206,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         });
     // image offsets: [x block][y block] per entry in plan order, after the zero block vacant slots point at
     std::vector<uint32_t> x_dw(plan.size()), y_dw(plan.size());
-    const size_t img0 = packed ? (size_t)kSwPackedMaxShort / 4 + 1 : 0;
-    size_t img_dw = img0;
+    img_dw = img0;
     {
         const int parts = (int)std::min<int64_t>(agx_host_threads(), std::max<int64_t>(1, (int64_t)plan.size() / 16384));
         std::vector<size_t> part_sum((size_t)parts + 1, 0);
@@ -955,11 +1238,12 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             }
         });
     }
-    const double t_waves = now_ms();
+    t_waves = now_ms();
 
     // ---- group records, written straight into pinned staging when there is a device
-    const size_t groups_bytes = n_groups * (packed ? sizeof(SwGroup2) : sizeof(SwGroup)), waves_bytes = waves.size() * sizeof(SwWave);
-    std::vector<uint8_t> groups_host; // plan-only: no pinned memory without a device
+    groups_bytes = n_groups * (packed ? sizeof(SwGroup2) : sizeof(SwGroup));
+    waves_bytes = waves.size() * sizeof(SwWave);
+    n_waves_total = waves.size();
     void *groups_data = nullptr;
     if (ctx) {
         rc = h_groups.alloc(ctx, groups_bytes);
@@ -995,16 +1279,21 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                         reinterpret_cast<SwGroup *>(groups_data)[q.group0 + (size_t)g] = SwGroup{xd, yd, ll, outi};
                 }
         });
-    const double t_records = now_ms();
+    t_records = now_ms();
 
+    } // host-made plan
     b->launches = launches;
     b->info.n_pairs = n_pairs;
     b->info.cells = cells;
     b->info.padded_cells = padded;
     b->info.input_bytes = (int64_t)(img_dw * 4 + groups_bytes + waves_bytes);
     b->info.n_launches = (int32_t)launches.size();
-    b->info.n_waves = (int32_t)waves.size();
+    b->info.n_waves = (int32_t)n_waves_total;
+    b->info.planned_on_device = device_plan ? 1 : 0;
     if (!ctx) { // planning only
+        if (trace)
+            fprintf(stderr, "[agx_sw_batch_create, plan only] %lld pairs: pass A %.2f ms | tiling %.2f, sort %.2f, waves %.2f, records %.2f\n",
+                    (long long)n_pairs, t_pass_a - t_begin, t_plan - t_pass_a, t_sort - t_plan, t_waves - t_sort, t_records - t_waves);
         *out = b;
         b = nullptr;
         return AGX_OK;
@@ -1018,8 +1307,8 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     }
     const double t_joined = now_ms();
     rc = b->img.alloc(ctx, std::max<size_t>(img_dw, 4) * 4);
-    if (!rc) rc = b->groups.alloc(ctx, groups_bytes);
-    if (!rc) rc = b->waves.alloc(ctx, waves_bytes);
+    if (!rc && !device_plan) rc = b->groups.alloc(ctx, groups_bytes); // (the device planner has written its own already)
+    if (!rc && !device_plan) rc = b->waves.alloc(ctx, waves_bytes);
     if (!rc && matrix) rc = b->table.alloc(ctx, table.size() * sizeof(int16_t));
     if (!rc) rc = b->scores.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(int32_t)); // +1: spare slot of vacant packed halves
     if (!rc) rc = b->out_stage.alloc(ctx, ((size_t)n_pairs + 1) * sizeof(int32_t));
@@ -1027,8 +1316,10 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
-    if (groups_bytes) e = hipMemcpyAsync(b->groups.p, h_groups.p, groups_bytes, hipMemcpyHostToDevice, cs);
-    if (e == hipSuccess && waves_bytes) e = hipMemcpyAsync(b->waves.p, h_waves.p, waves_bytes, hipMemcpyHostToDevice, cs);
+    if (device_plan) // the records are being written on the planning stream: the pack kernel comes behind them
+        e = hipStreamWaitEvent(cs, ctx->plan_done, 0);
+    if (e == hipSuccess && !device_plan && groups_bytes) e = hipMemcpyAsync(b->groups.p, h_groups.p, groups_bytes, hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess && !device_plan && waves_bytes) e = hipMemcpyAsync(b->waves.p, h_waves.p, waves_bytes, hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && matrix)
         e = hipMemcpyAsync(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice, cs);
     // pairs with an empty side are never touched by a kernel: their score is this zero
@@ -1042,10 +1333,10 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         // the DNA-coded cell adds (mismatch + |gf|) and a table byte: both must be non-negative bytes
         const bool dna = family == 2 && prm.delta < 128 && prm.hd >= prm.delta && !(dna_knob && dna_knob[0] == '0');
         const int pr = dna // the biased packed fill has a DNA-coded cell: its pack kernel decides per wavefront
-                           ? agx_sw_pack_dna_launch((const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base, b->groups.p, b->waves.p,
-                                                    (uint32_t)waves.size(), (uint32_t)n_pairs, (uint32_t *)b->img.p, (uint32_t *)d_flag.p,
+                           ? agx_sw_pack_dna_launch((const uint8_t *)d_raw.p + kRawPad, (const uint64_t *)d_off.p, raw_base, b->groups.p, b->waves.p,
+                                                    (uint32_t)n_waves_total, (uint32_t)n_pairs, (uint32_t *)b->img.p, (uint32_t *)d_flag.p,
                                                     n_cu, cs)
-                           : agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p, (const uint64_t *)d_off.p, raw_base,
+                           : agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p + kRawPad, (const uint64_t *)d_off.p, raw_base,
                                                 b->groups.p, (uint32_t)n_groups, (uint32_t)n_pairs, (uint32_t *)b->img.p,
                                                 (const uint8_t *)d_code.p, (uint32_t *)d_flag.p, n_cu, cs);
         if (pr) {
@@ -1059,6 +1350,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         agx_set_error("agx_sw_batch_create: upload -> %s", hipGetErrorString(e));
         return AGX_E_HIP;
     }
+    if (device_plan) b->info.padded_cells = (int64_t) * (const unsigned long long *)dp.h_padded.p; // (the planning stream ended before the pack kernel began)
     if (flag[0]) {
         if (matrix)
             agx_set_error("pair %u contains a byte outside the substitution matrix's alphabet", flag[1]);
@@ -1068,9 +1360,9 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     }
     if (trace)
         fprintf(stderr,
-                "[agx_sw_batch_create] %lld pairs: pass A %.2f ms | tiling %.2f, sort %.2f, waves %.2f, records %.2f | waited %.2f ms more "
+                "[agx_sw_batch_create] %lld pairs%s: pass A %.2f ms | tiling %.2f, sort %.2f, waves %.2f, records %.2f | waited %.2f ms more "
                 "for the upload of %.1f MB | device pack + sync %.2f ms\n",
-                (long long)n_pairs, t_pass_a - t_begin, t_plan - t_pass_a, t_sort - t_plan, t_waves - t_sort, t_records - t_waves,
+                (long long)n_pairs, device_plan ? " (planned on the device)" : "", t_pass_a - t_begin, t_plan - t_pass_a, t_sort - t_plan, t_waves - t_sort, t_records - t_waves,
                 t_joined - t_records, raw_bytes / 1e6, now_ms() - t_joined);
     *out = b;
     b = nullptr;

@@ -99,3 +99,30 @@ int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_wide_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                              const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
+
+// ---- device-side planning (agx_sw_plan_kernel.hip): the O(pairs) passes of the planner as kernels
+constexpr uint32_t kSwPlanEmptyKey = 1u << 27;           // sort key of a pair with an empty side: behind every bucket
+constexpr uint32_t kSwPlanWaveKeyMax = (1u << 24) - 1u;  // wave dispatch key = this - steps x columns per lane
+constexpr int kSwPlanBuckets = kSwNumClasses * 64;       // bucket id = class index * 64 + (64 - lanes per group)
+struct SwPlanArgs {
+    const uint32_t *len;        // the caller's len[], on the device
+    uint32_t n_pairs, n_fill;   // pairs / pairs with work
+    const uint32_t *seg_first;  // tiling table: segments of shorter length lx are [seg_first[lx], seg_first[lx + 1])
+    const uint32_t *segs;       // ly_from | class index << 16 | lanes per group << 24
+    uint32_t longest;           // longest longer side of the batch
+    const uint32_t *buckets;    // kSwPlanBuckets x {first entry, entries, first group, groups, first wave}
+    uint32_t img0;              // image word the first block starts at
+    int slots;                  // pairs per lane group (2 = packed kernels)
+    uint32_t n_waves;
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b;                       // n_pairs words each
+    uint32_t *wave_keys_a, *wave_keys_b, *wave_ids_a, *wave_ids_b;   // n_waves words each
+    SwWave *waves_tmp, *waves;                                        // n_waves records each; `waves` receives the dispatch order
+    uint32_t *groups;                                                 // SwGroup / SwGroup2 records
+    unsigned long long *padded;                                       // += padded cells
+    void *temp;
+    size_t temp_bytes;
+    int n_cu;
+};
+size_t agx_sw_plan_temp_bytes(uint32_t n_pairs, uint32_t n_waves);
+int agx_sw_plan_launch(const SwPlanArgs &a, hipStream_t s);
+void agx_sw_plan_preload();

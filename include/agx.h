@@ -80,6 +80,10 @@ int agx_ctx_sync(agx_ctx *ctx);
 #define AGX_SW_KERNEL_INT32 1         /* one pair per lane group, int32 state (BASELINE config 2 as worded) */
 #define AGX_SW_KERNEL_PACKED_SIGNED 2 /* two pairs per lane group, signed int16 halves */
 #define AGX_SW_KERNEL_PACKED_BIASED 3 /* two pairs per lane group, biased unsigned halves (the default where it fits) */
+#define AGX_OPT_SW_PLANNER 2 /* where the Smith-Waterman planner's per-pair passes run; same records, same scores */
+#define AGX_SW_PLANNER_AUTO 0   /* on the device for large mixed batches of the packed biased fill, else on the host */
+#define AGX_SW_PLANNER_HOST 1   /* always on the host (threaded) */
+#define AGX_SW_PLANNER_DEVICE 2 /* on the device whenever the batch-level rules allow it, whatever the batch size */
 int agx_ctx_set_option(agx_ctx *ctx, int key, int64_t value);
 /* Brings the HIP runtime and the process-wide contexts of these devices up (the ones agx_*_devices / agx_*_multi /
  * agx_pairHMM use) without computing anything: about 0.2 s that a host can spend on another thread while it
@@ -120,6 +124,8 @@ typedef struct agx_sw_info {
     int64_t input_bytes;  /* bytes of the packed device image the kernels read */
     int32_t n_launches;   /* kernel launches per agx_sw_batch_launch() */
     int32_t n_waves;      /* wavefronts over all launches */
+    int32_t planned_on_device; /* 1 = the per-pair passes of the planner ran as kernels (AGX_OPT_SW_PLANNER) */
+    int32_t reserved;
 } agx_sw_info;
 
 /* Scoring of the fill (8f n3: the reference's GPU variants carry these as kernel arguments but

@@ -320,3 +320,48 @@ def test_all_four_cells_of_the_biased_fill(ctx, oracle):
         for long_rows in (False, True):
             b = batch(alpha, long_rows)
             assert np.array_equal(ctx.sw_score(b), oracle.sw_batch(b)), (alpha.size, long_rows)
+
+
+def _planned(ctx, b, planner):
+    ctx.set_option(agx.OPT_SW_PLANNER, planner)
+    try:
+        dev = ctx.sw_batch(b)
+    finally:
+        ctx.set_option(agx.OPT_SW_PLANNER, agx.SW_PLANNER_AUTO)
+    dev.launch()
+    s, i = dev.scores(), dev.info()
+    dev.close()
+    return s, i
+
+
+@pytest.mark.parametrize("n,lo,hi,seed", [(80000, 32, 512, 21), (150000, 20, 300, 22), (70001, 100, 700, 23)])
+def test_device_planner_writes_the_host_planner_s_plan(ctx, oracle, n, lo, hi, seed):
+    """the planner's per-pair passes as kernels (agx_sw_plan_kernel.hip: keys, stable radix sort,
+    scan, records, wave order).  Same tiling table, same keys, stable sorts: the plan must be the host planner's --
+    same wave count, padded cells, image size, one launch -- and the scores bit-exact against the oracle."""
+    b = synth.sw_pairs(n, lo, hi, seed=seed, related_frac=0.3)
+    b.len[2 * 17] = 0          # a pair with an empty side: sorts behind every bucket, scores 0
+    b.len[2 * 4097 + 1] = 0
+    s_host, i_host = _planned(ctx, b, agx.SW_PLANNER_HOST)
+    s_dev, i_dev = _planned(ctx, b, agx.SW_PLANNER_DEVICE)
+    assert i_host.planned_on_device == 0 and i_dev.planned_on_device == 1
+    for f in ("n_pairs", "cells", "padded_cells", "input_bytes", "n_launches", "n_waves"):
+        assert getattr(i_host, f) == getattr(i_dev, f), f
+    assert np.array_equal(s_host, s_dev) and s_dev[17] == 0 and s_dev[4097] == 0
+    sub = np.arange(0, n, 7)
+    assert np.array_equal(s_dev[sub], oracle_api.sw_batch_mt(oracle, b.subset(sub)))
+
+
+def test_device_planner_leaves_small_uniform_and_tail_batches_to_the_host(ctx, oracle):
+    """The batch-level rules that need another tiling (tail regime, dominant shape) and uniform batches stay with the
+    host planner even when the device planner is asked for; AUTO takes the device only from 49 152 pairs on."""
+    for b in (synth.sw_pairs(4000, 32, 512, seed=31), synth.sw_pairs(65536, 150, 150, seed=2), synth.sw_pairs(30000, 1, 40, seed=32)):
+        s, i = _planned(ctx, b, agx.SW_PLANNER_DEVICE)
+        assert i.planned_on_device == 0
+        assert np.array_equal(s[::5], oracle_api.sw_batch_mt(oracle, b.subset(np.arange(0, b.n_pairs, 5))))
+    b = synth.sw_pairs(40000, 32, 512, seed=33)
+    assert _planned(ctx, b, agx.SW_PLANNER_AUTO)[1].planned_on_device == 0
+    b = synth.sw_pairs(131072, 32, 512, seed=34)
+    s, i = _planned(ctx, b, agx.SW_PLANNER_AUTO)
+    assert i.planned_on_device == 1
+    assert np.array_equal(s[::16], oracle_api.sw_batch_mt(oracle, b.subset(np.arange(0, b.n_pairs, 16))))
