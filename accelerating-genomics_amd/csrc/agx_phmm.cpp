@@ -633,6 +633,9 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
 
 } // namespace
 
+// agx_phmm_forward sends a batch of more than two of these through in pieces of whole regions (see there)
+constexpr double kPhmmPieceCells = 4.0e9;
+
 struct agx_phmm_batch {
     agx_ctx *ctx = nullptr; // retained
     int precision = AGX_PHMM_F64;
@@ -701,8 +704,16 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     seed.gatk_prior = gatk_prior;
     std::vector<Plan> &gen0 = seed.gen0;
     int64_t n_pairs = 0, cells = 0;
+    // A descriptor whose regions name only part of its reads and haplotypes -- a shard of agx_phmm_forward_devices, a
+    // piece of agx_phmm_forward: they keep the caller's absolute indices -- is narrowed to that part first: the image
+    // holds what the regions use, not every read and haplotype of the caller (each of config 5's eight shards carried
+    // the whole batch's 33 MB before).  r_base / h_base: what error messages add to name the caller's numbers.
+    agx_phmm_desc view;
+    std::vector<uint32_t> view_rr, view_rh;
+    uint32_t r_base = 0, h_base = 0;
     {
         const uint32_t ng = d->n_regions;
+        uint32_t rmin = d->n_reads, rmax = 0, hmin = d->n_haps, hmax = 0;
         for (uint32_t g = 0; g < ng; ++g) {
             const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1];
             const uint32_t h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
@@ -710,17 +721,37 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                 agx_set_error("region %u: read/haplotype ranges out of order or out of bounds", g);
                 return AGX_E_ARG;
             }
+            rmin = std::min(rmin, r0), rmax = std::max(rmax, r1);
+            hmin = std::min(hmin, h0), hmax = std::max(hmax, h1);
         }
+        if (ng && (rmin > 0 || rmax < d->n_reads || hmin > 0 || hmax < d->n_haps)) {
+            view = *d;
+            view_rr.assign(d->region_read, d->region_read + ng + 1);
+            view_rh.assign(d->region_hap, d->region_hap + ng + 1);
+            for (uint32_t &v : view_rr) v -= rmin;
+            for (uint32_t &v : view_rh) v -= hmin;
+            view.region_read = view_rr.data();
+            view.region_hap = view_rh.data();
+            view.read_off = d->read_off + rmin; // offsets into the tracks stay absolute
+            view.hap_off = d->hap_off + hmin;
+            view.n_reads = rmax - rmin;
+            view.n_haps = hmax - hmin;
+            r_base = rmin, h_base = hmin;
+            d = &view;
+        }
+    }
+    {
+        const uint32_t ng = d->n_regions;
         // lengths are checked once per read / haplotype, not once per pair
         for (uint32_t r = 0; d->read_off && r < d->n_reads; ++r)
             if (d->read_off[r + 1] - d->read_off[r] > AGX_PHMM_MAX_READ_LEN) {
-                agx_set_error("read %u: %llu bases exceed the supported %d", r, (unsigned long long)(d->read_off[r + 1] - d->read_off[r]),
+                agx_set_error("read %u: %llu bases exceed the supported %d", r + r_base, (unsigned long long)(d->read_off[r + 1] - d->read_off[r]),
                               AGX_PHMM_MAX_READ_LEN);
                 return AGX_E_LIMIT;
             }
         for (uint32_t h = 0; d->hap_off && h < d->n_haps; ++h)
             if (d->hap_off[h + 1] - d->hap_off[h] > AGX_PHMM_MAX_HAP_LEN) {
-                agx_set_error("haplotype %u: %llu bases exceed the supported %d", h, (unsigned long long)(d->hap_off[h + 1] - d->hap_off[h]),
+                agx_set_error("haplotype %u: %llu bases exceed the supported %d", h + h_base, (unsigned long long)(d->hap_off[h + 1] - d->hap_off[h]),
                               AGX_PHMM_MAX_HAP_LEN);
                 return AGX_E_LIMIT;
             }
@@ -1345,13 +1376,68 @@ int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info)
 
 int agx_phmm_forward(agx_ctx *ctx, const agx_phmm_desc *d, int precision, double *log10_lik)
 {
-    agx_phmm_batch *b = nullptr;
-    int rc = agx_phmm_batch_create(ctx, d, precision, &b);
+    AGX_GUARD_BEGIN
+    // A large batch goes through in pieces of whole regions (cut by cells, like the shards of agx_phmm_forward_devices):
+    // piece k + 1 is enumerated, planned and uploaded while piece k is being filled, so the host's 3-4 ms for config 5's
+    // 262 144 pairs hide behind the 12 ms of fills instead of standing in front of them.
+    int pieces = 1;
+    if (ctx && d && d->n_regions >= 2 && d->region_read && d->region_hap && d->read_off && d->hap_off) {
+        double cells = 0;
+        for (uint32_t g = 0; g < d->n_regions; ++g) {
+            const uint32_t r0 = d->region_read[g], r1 = d->region_read[g + 1], h0 = d->region_hap[g], h1 = d->region_hap[g + 1];
+            if (r1 < r0 || h1 < h0 || r1 > d->n_reads || h1 > d->n_haps) {
+                cells = 0; // malformed: let the one-batch path report it
+                break;
+            }
+            cells += (double)(d->read_off[r1] - d->read_off[r0]) * (double)(d->hap_off[h1] - d->hap_off[h0]);
+        }
+        pieces = (int)std::min<double>({8.0, cells / kPhmmPieceCells, (double)d->n_regions});
+        if (pieces < 2) pieces = 1;
+    }
+    if (pieces == 1) {
+        agx_phmm_batch *b = nullptr;
+        int rc = agx_phmm_batch_create(ctx, d, precision, &b);
+        if (rc) return rc;
+        rc = agx_phmm_batch_launch(b);
+        if (!rc) rc = agx_phmm_batch_results(b, log10_lik, nullptr);
+        agx_phmm_batch_destroy(b);
+        return rc;
+    }
+    std::vector<uint32_t> cut((size_t)pieces + 1);
+    int rc = agx_phmm_shard_cuts(d, pieces, cut.data());
     if (rc) return rc;
-    rc = agx_phmm_batch_launch(b);
-    if (!rc) rc = agx_phmm_batch_results(b, log10_lik, nullptr);
-    agx_phmm_batch_destroy(b);
-    return rc;
+    std::vector<agx_phmm_batch *> bs((size_t)pieces, nullptr);
+    struct Cleanup {
+        std::vector<agx_phmm_batch *> &v;
+        ~Cleanup()
+        {
+            for (agx_phmm_batch *b : v) agx_phmm_batch_destroy(b);
+        }
+    } cleanup{bs};
+    std::vector<int64_t> first_out((size_t)pieces + 1, 0);
+    for (int k = 0; k < pieces; ++k) {
+        int64_t n = 0;
+        for (uint32_t g = cut[(size_t)k]; g < cut[(size_t)k + 1]; ++g)
+            n += (int64_t)(d->region_read[g + 1] - d->region_read[g]) * (d->region_hap[g + 1] - d->region_hap[g]);
+        first_out[(size_t)k + 1] = first_out[(size_t)k] + n;
+        if (cut[(size_t)k + 1] <= cut[(size_t)k]) continue;
+        agx_phmm_desc sub = *d;
+        sub.region_read = d->region_read + cut[(size_t)k]; // absolute read / haplotype indices stay valid
+        sub.region_hap = d->region_hap + cut[(size_t)k];
+        sub.n_regions = cut[(size_t)k + 1] - cut[(size_t)k];
+        rc = agx_phmm_batch_create(ctx, &sub, precision, &bs[(size_t)k]);
+        if (!rc) rc = agx_phmm_batch_launch(bs[(size_t)k]);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < pieces; ++k) {
+        if (!bs[(size_t)k]) continue;
+        rc = agx_phmm_batch_results(bs[(size_t)k], log10_lik + first_out[(size_t)k], nullptr);
+        if (rc) return rc;
+        agx_phmm_batch_destroy(bs[(size_t)k]);
+        bs[(size_t)k] = nullptr;
+    }
+    return AGX_OK;
+    AGX_GUARD_END("agx_phmm_forward")
 }
 
 int agx_phmm_shard_cuts(const agx_phmm_desc *d, int n_shards, uint32_t *cut)

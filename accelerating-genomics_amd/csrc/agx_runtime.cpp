@@ -207,7 +207,7 @@ void agx_pool_run(int parts, const std::function<void(int)> &task)
 
 namespace {
 
-constexpr size_t kPoolMaxBlocks = 48;
+constexpr size_t kPoolMaxBlocks = 512; // (a one-shot call in pieces keeps 8-16 batches alive: 48 blocks overflowed into hipFree, which waits for the running fill)
 constexpr size_t kDevPoolMaxBytes = (size_t)24 << 30; // of 288 GB HBM
 constexpr size_t kPinPoolMaxBytes = (size_t)4 << 30;
 

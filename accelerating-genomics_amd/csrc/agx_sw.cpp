@@ -203,6 +203,9 @@ Tiling choose_tiling_uniform(const double *costs, int slots, int lx, int ly, int
     return best;
 }
 
+// agx_sw_score sends a large batch through in pieces (upload of piece k + 1 beside the fill of piece k)
+constexpr uint64_t kPieceBytes = (uint64_t)64 << 20;
+constexpr int64_t kPieceMinPairs = 65536;
 constexpr size_t kRawPad = 64;       // bytes in front of and behind the uploaded sequences (16-byte aligned pieces, agx_sw_pack_kernel.hip)
 constexpr uint8_t kClsEmpty = 255;   // an empty side: nothing to fill
 constexpr uint8_t kClsUntiled = 254; // pass A done, no tiling yet
@@ -744,7 +747,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                     const int slot = k % kRing;
                     const size_t n = std::min(kSlice, (size_t)raw_bytes - at);
                     if (k >= kRing && hipEventSynchronize(done[slot]) != hipSuccess) r = AGX_E_HIP;
-                    const int parts = 4;
+                    const int parts = std::max(1, std::min(8, agx_host_threads())); // 4 copied 16 MB in 0.4 ms, above the slice's 0.29 ms DMA
                     const size_t per = (n + parts - 1) / parts;
                     agx_pool_run(parts, [&](int t) {
                         const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
@@ -1459,13 +1462,62 @@ int agx_sw_batch_info(const agx_sw_batch *b, agx_sw_info *info)
 int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const uint32_t *len, int64_t n_pairs,
                  int32_t *scores)
 {
-    agx_sw_batch *b = nullptr;
-    int rc = agx_sw_batch_create(ctx, bases, off, len, n_pairs, &b);
-    if (rc) return rc;
-    rc = agx_sw_batch_launch(b);
-    if (!rc) rc = agx_sw_batch_scores(b, scores);
-    agx_sw_batch_destroy(b); // its buffers return to the context's pools for the next call
-    return rc;
+    AGX_GUARD_BEGIN
+    // A large batch goes through in contiguous pieces of about 64 MB of sequence: piece k + 1 is uploaded, planned and
+    // packed (copy and planning streams) while piece k is being filled (launch stream), so the call lasts about as
+    // long as the upload plus the last piece's fill instead of upload + fill (1 048 576 mixed pairs, 573 MB, from
+    // page-locked memory: 20.7 -> see DESIGN.md section 7).  Scores are fetched at the end, piece by piece, into the
+    // caller's array.
+    int pieces = 1;
+    if (ctx && n_pairs >= 2 * kPieceMinPairs && len) {
+        std::vector<uint64_t> part((size_t)agx_host_threads(), 0);
+        agx_parallel_for(n_pairs, 65536, [&](int64_t lo, int64_t hi, int t) {
+            uint64_t s = 0;
+            for (int64_t p = 2 * lo; p < 2 * hi; ++p) s += len[p];
+            part[(size_t)t] = s;
+        });
+        uint64_t bytes = 0;
+        for (uint64_t v : part) bytes += v;
+        pieces = (int)std::min<uint64_t>({(uint64_t)16, bytes / kPieceBytes, (uint64_t)(n_pairs / kPieceMinPairs)});
+        if (pieces < 2) pieces = 1;
+    }
+    if (pieces == 1) {
+        agx_sw_batch *b = nullptr;
+        int rc = agx_sw_batch_create(ctx, bases, off, len, n_pairs, &b);
+        if (rc) return rc;
+        rc = agx_sw_batch_launch(b);
+        if (!rc) rc = agx_sw_batch_scores(b, scores);
+        agx_sw_batch_destroy(b); // its buffers return to the context's pools for the next call
+        return rc;
+    }
+    std::vector<agx_sw_batch *> bs((size_t)pieces, nullptr);
+    struct Cleanup {
+        std::vector<agx_sw_batch *> &v;
+        ~Cleanup()
+        {
+            for (agx_sw_batch *b : v) agx_sw_batch_destroy(b);
+        }
+    } cleanup{bs};
+    auto cut = [&](int k) { return n_pairs * k / pieces; };
+    for (int k = 0; k < pieces; ++k) {
+        const int64_t lo = cut(k), hi = cut(k + 1);
+        int rc = agx_sw_batch_create(ctx, bases, off + 2 * lo, len + 2 * lo, hi - lo, &bs[(size_t)k]);
+        if (rc == AGX_E_SYMBOL || rc == AGX_E_LIMIT) { // the messages name pair numbers: of the whole batch, not of the piece
+            unsigned long long p = 0;
+            char rest[400] = "";
+            if (sscanf(agx_last_error(), "pair %llu%399[^\n]", &p, rest) >= 1) agx_set_error("pair %llu%s", p + (unsigned long long)lo, rest);
+        }
+        if (!rc) rc = agx_sw_batch_launch(bs[(size_t)k]);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < pieces; ++k) {
+        const int rc = agx_sw_batch_scores(bs[(size_t)k], scores + cut(k));
+        if (rc) return rc;
+        agx_sw_batch_destroy(bs[(size_t)k]);
+        bs[(size_t)k] = nullptr;
+    }
+    return AGX_OK;
+    AGX_GUARD_END("agx_sw_score")
 }
 
 int agx_sw_shard_cuts(const uint32_t *len, int64_t n_pairs, int n_shards, int64_t *cut)

@@ -412,3 +412,21 @@ def test_gatk_prior_option(ctx, oracle, golden_dir):
     # 5e-7 with the reference's prior, 1.2e-6 on one pair with this one -- 4e-6 of a log10 of -3.65; the plain cell 5.6e-7)
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA | agx.PHMM_GATK_PRIOR), l_ref) <= 2e-6
     assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA | agx.PHMM_GATK_PRIOR), l_ref) <= 1e-12
+
+
+def test_one_shot_forward_of_a_large_batch_runs_in_pieces(ctx, oracle):
+    """agx_phmm_forward sends a batch of more than 8e9 cells through in pieces of whole regions (piece k + 1 planned and
+    uploaded beside the fill of piece k): the results are those of the one-batch path, bit for bit in double."""
+    p = synth.phmm_regions(150, 32, 16, 250, 500, seed=61, jitter=20)
+    assert p.cells() > 8.0e9 * 1.05
+    for prec in (agx.PHMM_F64, agx.PHMM_F32_FMA):
+        got = ctx.phmm_forward(p, prec)
+        dev = ctx.phmm_batch(p, prec)
+        dev.launch()
+        want, _ = dev.results()
+        dev.close()
+        assert np.array_equal(got, want)
+    sub = p.regions(140, 143)
+    first = int(sum((p.rreg[g + 1] - p.rreg[g]) * (p.hreg[g + 1] - p.hreg[g]) for g in range(140)))
+    _, l_ref = oracle.phmm_batch(sub, 0)
+    assert np.array_equal(ctx.phmm_forward(p, agx.PHMM_F64)[first:first + sub.n_pairs], l_ref)

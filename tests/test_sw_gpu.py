@@ -365,3 +365,22 @@ def test_device_planner_leaves_small_uniform_and_tail_batches_to_the_host(ctx, o
     s, i = _planned(ctx, b, agx.SW_PLANNER_AUTO)
     assert i.planned_on_device == 1
     assert np.array_equal(s[::16], oracle_api.sw_batch_mt(oracle, b.subset(np.arange(0, b.n_pairs, 16))))
+
+
+def test_one_shot_score_of_a_large_batch_runs_in_pieces(ctx, oracle):
+    """agx_sw_score sends a batch of more than about 128 MB through in contiguous pieces (piece k + 1 uploaded and planned
+    beside the fill of piece k): same scores as the one-batch path, errors name pair numbers of the WHOLE batch."""
+    b = synth.sw_pairs(300000, 150, 450, seed=41, related_frac=0.2)
+    assert b.bases.size > (160 << 20)
+    got = ctx.sw_score(b)
+    dev = ctx.sw_batch(b)
+    dev.launch()
+    assert np.array_equal(got, dev.scores())
+    dev.close()
+    sub = np.arange(0, b.n_pairs, 37)
+    assert np.array_equal(got[sub], oracle_api.sw_batch_mt(oracle, b.subset(sub)))
+    bad = synth.SWBatch(b.bases.copy(), b.off, b.len)
+    bad.bases[int(b.off[2 * 250001]) + 3] = 0      # the padding symbol inside a pair of the second piece
+    with pytest.raises(agx.AgxError) as e:
+        ctx.sw_score(bad)
+    assert e.value.code == agx.E_SYMBOL and "pair 250001 " in str(e.value)
