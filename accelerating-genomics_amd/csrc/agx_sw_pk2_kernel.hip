@@ -409,7 +409,8 @@ __global__ void __launch_bounds__(256) sw_fill_pk2(const SwParams prm, const uin
 
 // Mixed batches: ONE launch for every lane-tiling class.  Each wavefront reads its class (columns per lane)
 // from its record and runs that class's fill; the kernel is allocated the registers of the widest class
-// (100 VGPRs, five waves per SIMD -- the fill is bound by VALU issue, not by occupancy).  Against one launch
+// (202-206 VGPRs as its code objects state them -- tools/kernel_resources.py --, two waves per SIMD: the fill is bound by
+// VALU issue, not by occupancy).  Against one launch
 // per class this (a) lets the planner use every width, so padding shrinks, (b) dispatches the waves of ALL
 // classes longest first, (c) has no stream fork/join and no per-launch ramp.
 template <int KC>

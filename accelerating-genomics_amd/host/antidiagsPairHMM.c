@@ -21,11 +21,19 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include "agx.h"
 #include "agx_fmt.h"
 #include "agx_pipe.h"
+
+static double seconds(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 typedef struct {
     agx_phmm_reader *reader;
@@ -33,6 +41,7 @@ typedef struct {
     agx_pipe q;
     int rc;
     char err[512];
+    double t_parse; /* AGX_TRACE_CLI: time inside the reader */
 } parse_stage;
 
 static void *parser_main(void *arg)
@@ -40,7 +49,9 @@ static void *parser_main(void *arg)
     parse_stage *s = (parse_stage *)arg;
     while (!agx_phmm_reader_done(s->reader)) {
         agx_phmm_text *t = NULL;
+        const double ta = seconds();
         const int rc = agx_phmm_reader_next(s->reader, s->chunk_pairs, &t);
+        s->t_parse += seconds() - ta;
         if (rc != AGX_OK) {
             s->rc = rc;
             snprintf(s->err, sizeof s->err, "%s", agx_last_error());
@@ -60,12 +71,15 @@ typedef struct {
 typedef struct {
     const int *devices; /* NULL: devices 0 .. n-1 */
     int n;
+    double t_warm;
 } warm_t;
 
 static void *warm_main(void *arg)
 {
     warm_t *w = (warm_t *)arg;
+    const double ta = seconds();
     (void)agx_warmup_devices(w->devices, w->n); /* HIP start-up beside the parsing; a failure shows at the first batch */
+    w->t_warm = seconds() - ta;
     return NULL;
 }
 
@@ -73,6 +87,7 @@ typedef struct {
     agx_pipe q;
     FILE *out;
     uint32_t batches; /* `#batch:` lines printed so far */
+    double t_print;   /* AGX_TRACE_CLI: time spent formatting and writing */
 } print_stage;
 
 static void *printer_main(void *arg)
@@ -81,6 +96,7 @@ static void *printer_main(void *arg)
     for (;;) {
         scored_chunk *c = (scored_chunk *)agx_pipe_pop(&s->q);
         if (!c) break;
+        const double ta = seconds();
         const agx_phmm_desc *d = &c->text->desc;
         int64_t k = 0;
         /* every value is formatted once (agx_fmt.h: printf's "%f\n" byte for byte, at a tenth of its cost) and written
@@ -104,6 +120,7 @@ static void *printer_main(void *arg)
         free(c->lh);
         agx_phmm_text_free(c->text);
         free(c);
+        s->t_print += seconds() - ta;
     }
     return NULL;
 }
@@ -114,6 +131,8 @@ int main(int argc, const char *argv[])
         fprintf(stderr, "Usage: %s <input_file_r> <output_file>\n", argv[0]); /* :314-317 */
         return EXIT_FAILURE;
     }
+    const int trace = getenv("AGX_TRACE_CLI") != NULL; /* stage times on stderr, like the Smith-Waterman command line */
+    const double tr0 = seconds();
     parse_stage ps;
     memset(&ps, 0, sizeof ps);
     int rc = agx_phmm_reader_open(argv[1], &ps.reader);
@@ -143,6 +162,7 @@ int main(int argc, const char *argv[])
     agx_pipe_init(&pr.q, 2);
     pthread_t parser, printer, warmer;
     warm_t warm;
+    memset(&warm, 0, sizeof warm);
     warm.devices = n_dev ? devices : NULL;
     warm.n = n_dev ? n_dev : n_multi;
     if (pthread_create(&parser, NULL, parser_main, &ps) || pthread_create(&printer, NULL, printer_main, &pr) ||
@@ -151,13 +171,20 @@ int main(int argc, const char *argv[])
         return EXIT_FAILURE;
     }
     int status = EXIT_SUCCESS, truncated = 0, warm_joined = 0;
+    double t_wait = 0, t_warm_wait = 0, t_score = 0, t_push = 0;
+    long n_chunks = 0;
     for (;;) {
+        double ta = seconds();
         agx_phmm_text *t = (agx_phmm_text *)agx_pipe_pop(&ps.q);
+        t_wait += seconds() - ta;
         if (!t) break;
         if (!warm_joined) {
+            ta = seconds();
             pthread_join(warmer, NULL);
+            t_warm_wait = seconds() - ta;
             warm_joined = 1;
         }
+        ta = seconds();
         if (t->truncated) truncated = t->truncated;
         scored_chunk *c = (scored_chunk *)calloc(1, sizeof *c);
         double *lh = (double *)malloc(sizeof(double) * (size_t)(t->n_pairs ? t->n_pairs : 1));
@@ -180,9 +207,13 @@ int main(int argc, const char *argv[])
             while ((t = (agx_phmm_text *)agx_pipe_pop(&ps.q)) != NULL) agx_phmm_text_free(t);
             break;
         }
+        t_score += seconds() - ta;
         c->text = t;
         c->lh = lh;
+        ta = seconds();
         agx_pipe_push(&pr.q, c);
+        t_push += seconds() - ta;
+        n_chunks++;
     }
     pthread_join(parser, NULL);
     agx_pipe_close(&pr.q);
@@ -200,6 +231,11 @@ int main(int argc, const char *argv[])
         }
     }
     if (!warm_joined) pthread_join(warmer, NULL);
+    if (trace)
+        fprintf(stderr,
+                "[cli] %ld chunk(s): HIP start-up %.3f s (waited %.3f s more for it behind the first chunk), waited for the parser %.3f s "
+                "(parser busy %.3f s), device %.3f s, waited for the printer's queue %.3f s (printer busy %.3f s), total %.3f s\n",
+                n_chunks, warm.t_warm, t_warm_wait, t_wait, ps.t_parse, t_score, t_push, pr.t_print, seconds() - tr0);
     fclose(pr.out);
     agx_phmm_reader_close(ps.reader);
     /* everything is written: leave without tearing the HIP runtime down */

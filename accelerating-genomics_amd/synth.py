@@ -198,6 +198,21 @@ class PhmmBatch:
                          (self.hreg[lo : hi + 1] - np.uint32(h0)).astype(np.uint32))
 
 
+def phmm_repeat(b: PhmmBatch, times: int) -> PhmmBatch:
+    """The batch's regions `times` times over, each copy with reads and haplotypes of its own (a corpus replicated to
+    bench size: regions are repeated, reads are not concatenated)."""
+    nr, nh = int(b.rreg[-1]), int(b.hreg[-1])
+    nb, nc = int(b.roff[nr]), int(b.hoff[nh])
+    tile = lambda a, n: np.tile(a[:n], times)
+    roff = np.concatenate([b.roff[:nr].astype(np.uint64) + np.uint64(k * nb) for k in range(times)] + [np.array([times * nb], np.uint64)])
+    hoff = np.concatenate([b.hoff[:nh].astype(np.uint64) + np.uint64(k * nc) for k in range(times)] + [np.array([times * nc], np.uint64)])
+    ng = b.n_regions
+    rreg = np.concatenate([b.rreg[:ng].astype(np.uint32) + np.uint32(k * nr) for k in range(times)] + [np.array([times * nr], np.uint32)])
+    hreg = np.concatenate([b.hreg[:ng].astype(np.uint32) + np.uint32(k * nh) for k in range(times)] + [np.array([times * nh], np.uint32)])
+    return PhmmBatch(tile(b.read_bases, nb), tile(b.q_base, nb), tile(b.q_ins, nb), tile(b.q_del, nb), tile(b.q_gcp, nb), roff,
+                     tile(b.hap_bases, nc), hoff, rreg, hreg)
+
+
 def phmm_from_regions(regions) -> PhmmBatch:
     """regions: list of (reads, haps); read = (bases, qb, qi, qd, qg) byte strings, hap = bytes."""
     rb, qb, qi, qd, qg, hb = [], [], [], [], [], []

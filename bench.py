@@ -466,6 +466,41 @@ def main():
         c5m_dev.close()
         c5m_rel = float(np.max(np.abs(c5m_out[0] - c5_out[0]) / np.maximum(np.abs(c5_out[0]), 1e-300)))
 
+        # ---------------- the reference's own corpus shape: pairHMM/test_set/10s.in (7 regions, 3550 pairs, reads of 10-247
+        # bases against haplotypes of 41-263; committed as tests/golden/phmm_10s.in) with its regions repeated 19 times
+        # -- 67 450 pairs, 133 regions -- in bit-identical double and in packed float; and the mixed SW golden file's
+        # 256 pairs (lengths 32-512) 256 times over.  Mixed regions are where the PairHMM planner pads most.
+        corpus_legs = {}
+        gold = os.path.join(ROOT, "tests", "golden")
+        if os.path.exists(os.path.join(gold, "phmm_10s.in")):
+            corpus = synth.phmm_repeat(synth.parse_phmm_text(open(os.path.join(gold, "phmm_10s.in"), "rb").read()), 19)
+            for prec, name in ((agx.PHMM_F64, "f64"), (agx.PHMM_F32_FMA, "f32_fma")):
+                co_out = (agx.host_array(corpus.n_pairs, np.float64), None)
+                co_dev = ctx.phmm_batch(corpus, prec)
+                co_info = co_dev.info()
+                co_t = timed(co_dev, lambda: co_dev.results(co_out, want_sums=False), *few())
+                co_info = co_dev.info()
+                co_dev.close()
+                corpus_legs[name] = {"pairs_per_s": n_gpus * corpus.n_pairs * co_t["steps"] / co_t["dt"], "ms_per_step": co_t["dt"] / co_t["steps"] * 1e3,
+                                     "cells_per_s": n_gpus * corpus.cells() * co_t["steps"] / co_t["dt"],
+                                     "kernel_only_ms": co_t["back_to_back_launch_ms"], "launches_per_step": co_info.n_launches, "waves": co_info.n_waves,
+                                     "useful_cell_fraction": co_info.cells / max(1, co_info.padded_cells), "rescued_in_f64": int(co_info.n_rescued),
+                                     "log10_checksum": float(co_out[0].sum())}
+            corpus_legs["pairs"], corpus_legs["regions"], corpus_legs["cells"] = corpus.n_pairs, corpus.n_regions, corpus.cells()
+            corpus_legs["what"] = "tests/golden/phmm_10s.in (= the reference's pairHMM/test_set/10s.in) with its 7 regions repeated 19 times, per GPU"
+        if os.path.exists(os.path.join(gold, "sw_mixed.in")):
+            _, swm, _ = agx.read_sw_text(os.path.join(gold, "sw_mixed.in"))
+            swm = swm.subset(np.tile(np.arange(swm.n_pairs), 256))
+            sm_out = agx.host_array(swm.n_pairs, np.int32)
+            sm_dev = ctx.sw_batch(swm)
+            sm_info = sm_dev.info()
+            sm_t = timed(sm_dev, lambda: sm_dev.scores(sm_out), *few())
+            sm_dev.close()
+            corpus_legs["sw_mixed"] = {"gcups": n_gpus * swm.cells(sentinel=False) / 1e9 * sm_t["steps"] / sm_t["dt"], "ms_per_step": sm_t["dt"] / sm_t["steps"] * 1e3,
+                                       "pairs": swm.n_pairs, "kernel_only_ms": sm_t["back_to_back_launch_ms"], "launches_per_step": sm_info.n_launches,
+                                       "useful_cell_fraction": sm_info.cells / max(1, sm_info.padded_cells), "planned_on_device": int(sm_info.planned_on_device),
+                                       "what": "tests/golden/sw_mixed.in (256 pairs, lengths 32-512, newline sentinels as the reference keeps them) 256 times over, per GPU"}
+
         # ---------------- strong legs: ONE host batch of the full size, the same on every rank, cut by cells
         def per_rank_table(pairs, cells, t):
             """Every rank's shard and launch time, gathered to all ranks (6 numbers each)."""
@@ -605,6 +640,7 @@ def main():
                               fp64_fma=dict(leg(c5m_t, c5.n_pairs, "pairs_per_s"), unit="pairs/s",
                                             what="the weak leg's shard with explicit fma (AGX_PHMM_F64_FMA): 8 instead of 11 fp64 operations per cell",
                                             max_rel_diff_to_bit_identical=c5m_rel, tolerance_asked=1e-12))
+        out["corpus_10s"] = corpus_legs
         out["multi_one_process"] = multi_one
         out["one_shot"] = one
     # the figures of the other legs that a reader of the first few keys should not have to dig for
@@ -615,7 +651,11 @@ def main():
                      "config4_total_n_shards": out["config4"]["total"]["n_shards"],
                      "config5_shard_f64_pairs_per_s": out["config5"]["value"], "config5_total_f64_pairs_per_s": out["config5"]["total"]["value"],
                      "multi_one_process_config4_ms": multi_one.get("config4", {}).get("ms"), "multi_one_process_config5_ms": multi_one.get("config5", {}).get("ms"),
-                     "one_shot_config2_pinned_ms_min": one["config2_pinned"]["ms_min"], "one_shot_config3_ms_min": one["config3_pageable"]["ms_min"]})
+                     "one_shot_config2_pinned_ms_min": one["config2_pinned"]["ms_min"], "one_shot_config3_ms_min": one["config3_pageable"]["ms_min"],
+                     "corpus_10s_f64_pairs_per_s": corpus_legs.get("f64", {}).get("pairs_per_s"),
+                     "corpus_10s_f32_fma_pairs_per_s": corpus_legs.get("f32_fma", {}).get("pairs_per_s"),
+                     "corpus_10s_f64_useful_cell_fraction": corpus_legs.get("f64", {}).get("useful_cell_fraction"),
+                     "corpus_10s_f32_fma_useful_cell_fraction": corpus_legs.get("f32_fma", {}).get("useful_cell_fraction")})
     out["config"]["int32_gcups"], out["config"]["int32_ms_per_step"] = i32_leg["value"], i32_leg["ms_per_step"]
     out["config"]["other_legs"] = summ
     out["control_plane"] = control

@@ -45,7 +45,21 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_trace.csv"), recursive=T
         k = short(r["Kernel_Name"])
         res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"),
                   r.get("Workgroup_Size_X"), r.get("Grid_Size_X"))
-    print("## per-dispatch resources (kernel trace)\n")
+    # rocprofv3's VGPR_Count is a granulated figure (it showed 100 for sw_fill_pk2<38, 4>, whose code object says 193):
+    # the registers below are the code objects' own .vgpr_count / .agpr_count / .sgpr_count (tools/kernel_resources.py)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from kernel_resources import kernel_resources
+        code = kernel_resources()
+        fixed = {}
+        for k, v in res.items():
+            name = k.replace("void ", "")
+            hit = code.get(name) or next((code[c] for c in code if c[:60] == name), None)
+            fixed[k] = ((hit["vgpr"], hit["agpr"], hit["sgpr"]) + tuple(v[3:])) if hit else v
+        res = fixed
+    except Exception as e:  # the library is not there: the trace's own columns, with this warning
+        print("(code objects not readable here -- %s: VGPR / AGPR / SGPR are rocprofv3's granulated columns)\n" % e)
+    print("## per-dispatch resources (registers from the code objects, the rest from the kernel trace)\n")
     print("(LDS B is the static allocation only; the PairHMM kernels take their read tables as dynamic LDS: "
           "32 B x (steps + G - 1) rows per table in the packed kernel -- 4160 B per one-wave workgroup on config 3 -- "
           "and 33 B per row in the double kernel)\n")

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
 ctx = agx.Context(0)
 def timeit(dev, reps):
