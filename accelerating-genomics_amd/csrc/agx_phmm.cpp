@@ -633,6 +633,10 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
 
 } // namespace
 
+// accuracy guard of the packed float fill (PhUnderflow, agx_phmm.h): |log10 L| below this times sqrt(R) -> double.
+// 1.24 x the worst error found over 3.6 million pairs (reads of 10 ... 2000 bases, three error rates; tools/phmm_f32_guard_cal.py)
+constexpr double kGuardRef = 0.18, kGuardGatk = 0.40;
+
 // agx_phmm_forward sends a batch of more than two of these through in pieces of whole regions (see there)
 constexpr double kPhmmPieceCells = 4.0e9;
 
@@ -1192,7 +1196,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                                                        (const PhTab *)b->main.tabs.p,
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
                                                        mis_for_f, (double *)b->sums.p,
-                                                       PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1},
+                                                       PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1,
+                                                                   (double)(FLT_MAX / 16), (float)((b->gatk_prior ? kGuardGatk : kGuardRef) * 3.3219280948873623)},
                                                        cl.lds, st);
                 if (r) {
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));

@@ -96,10 +96,16 @@ __host__ __device__ static inline size_t ph_pk_tab_bytes(uint32_t rows) { return
 // reference order with probability tracks instead of Phred characters (pairHMM() seam).
 // The packed float fill counts the pairs whose sum came out below the float range (`below`; indices >= n_pairs are the
 // spare slot of vacant halves): the double rescue plan is launched only when that count is not zero.
+// Accuracy guard (round 3): the float recurrences lose about 1.1e-7 sqrt(R) of log10 L (2.7e-7 sqrt(R) with the GATK prior)
+// at worst -- tools/phmm_f32_guard_cal.py, profiles/r03h_f32_guard_cal.log -- which matters where |log10 L| is small: a
+// pair whose |log10 L| comes out below guard_k sqrt(R + 8) is handed to the double rescue plan like an underflowed one (its
+// sum is stored as 0).  guard_c = the float scaling constant FLT_MAX / 16, guard_k2 = guard_k log2(10); guard_k2 = 0: off.
 struct PhUnderflow {
     double below;
     uint32_t n_pairs;
     unsigned long long *count;
+    double guard_c;
+    float guard_k2;
 };
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,

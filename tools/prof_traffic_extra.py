@@ -5,7 +5,13 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
 ctx = agx.Context(0)
+c2 = synth.sw_pairs(65536, 150, 150, seed=2, related_frac=0.25)  # config 2: its pack kernel (grid 2048 workgroups)
+d2 = ctx.sw_batch(c2)
+d2.launch()
+print("c2 checksum", int(d2.scores().sum()), "raw bytes", c2.bases.size)
+d2.close()
 c4 = synth.sw_pairs((1 << 20) // 8, 32, 512, seed=4)
+print("c4 raw bytes", c4.bases.size)
 d4 = ctx.sw_batch(c4)
 for _ in range(4):
     d4.launch()

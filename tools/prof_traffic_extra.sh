@@ -13,9 +13,9 @@ for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
-    if "sw_fill" not in k and "phmm_fill" not in k: continue
-    f = sum(cs["FETCH_SIZE"]) / max(1, len(cs["FETCH_SIZE"])); w = sum(cs["WRITE_SIZE"]) / max(1, len(cs["WRITE_SIZE"]))
+    if not any(t in k for t in ("sw_fill", "phmm_fill", "sw_pack", "sw_plan", "DeviceRadixSort", "DeviceScan", "radix_sort", "scan")): continue
+    f = sum(cs["FETCH_SIZE"]) / max(1, len(cs["FETCH_SIZE"])); w = sum(cs["WRITE_SIZE"]) / max(1, len(cs["WRITE_SIZE"])); n = len(cs["FETCH_SIZE"])
     name = k.replace("(anonymous namespace)::", "")
-    out[name[:name.index("(")] if "(" in name else name] = {"fetch_kib_raw": f, "write_kib": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
+    out[(name[:name.index("(")] if "(" in name else name)[-90:]] = {"fetch_kib_raw": f, "write_kib": w, "hbm_bytes_corrected": (2 * f + w) * 1024, "dispatches": n}
 print(json.dumps(out, indent=1))
 PY
