@@ -87,6 +87,7 @@ struct agx_ctx {
     // upload of the sequences on `copy`, an event the pack kernel waits for, and the tiling table of the packed
     // biased fill on the device (made on first use, freed with the context).
     hipStream_t plan = nullptr;
+    int prio_hi = 0; // highest stream priority of the device (copy and planning streams)
     hipEvent_t plan_done = nullptr;
     void *sw_seg_first = nullptr, *sw_segs = nullptr;
     // options (agx_ctx_set_option)
@@ -139,6 +140,9 @@ static inline int agx_bind(const agx_ctx *c)
     AGX_HIP(hipSetDevice(c->device));
     return AGX_OK;
 }
+
+// memcpy with streaming stores, for staging copies into page-locked memory (agx_runtime.cpp)
+void agx_stream_copy(void *dst, const void *src, size_t n);
 
 // true when [p, p + bytes) lies in a block handed out by agx_host_alloc (page-locked: the device can DMA into or
 // out of it directly).  A registry of our own rather than hipPointerGetAttributes: asked about an ordinary

@@ -1,5 +1,6 @@
 // Context, error text, stopwatch, buffer pools and the host thread pool of the C-ABI
 // (include/agx.h, "runtime" section).
+#include <immintrin.h>
 #include <sched.h>
 #include <condition_variable>
 #include <deque>
@@ -203,6 +204,38 @@ void agx_pool_run(int parts, const std::function<void(int)> &task)
     if (sync.err) std::rethrow_exception(sync.err);
 }
 
+// ------------------------------------------------------------------ staging copies
+
+// memcpy for staging a pageable source into page-locked memory that only the DMA engine will read: streaming (non-temporal)
+// stores, so that the destination lines are not first read into the cache (a third of the memory traffic of a plain copy of
+// cold data) and the ring of staging blocks does not push the planner's arrays out of it.
+__attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+    if (head > n) head = n;
+    memcpy(dst, src, head);
+    dst += head, src += head, n -= head;
+    const size_t blocks = n / 128;
+    for (size_t k = 0; k < blocks; ++k) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src)), b = _mm256_loadu_si256((const __m256i *)(src + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + 64)), d = _mm256_loadu_si256((const __m256i *)(src + 96));
+        _mm256_stream_si256((__m256i *)(dst), a);
+        _mm256_stream_si256((__m256i *)(dst + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + 64), c);
+        _mm256_stream_si256((__m256i *)(dst + 96), d);
+        src += 128, dst += 128;
+    }
+    _mm_sfence();
+    memcpy(dst, src, n - blocks * 128);
+}
+
+void agx_stream_copy(void *dst, const void *src, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2 && n >= 4096) stream_copy_avx2((uint8_t *)dst, (const uint8_t *)src, n);
+    else memcpy(dst, src, n);
+}
+
 // ------------------------------------------------------------------ pooled buffers
 
 namespace {
@@ -213,7 +246,16 @@ constexpr size_t kPinPoolMaxBytes = (size_t)4 << 30;
 
 size_t round_block(size_t n)
 {
-    const size_t g = n < ((size_t)1 << 20) ? (size_t)4096 : (size_t)1 << 20;
+    // small blocks to 4 KB; from 1 MB on to an eighth of the size's power of two (at least 1 MB), so that requests a
+    // few per cent apart -- the pieces of a one-shot call -- share a size class: with 1 MB steps a later, slightly
+    // larger piece found every block of its class taken by smaller ones and fell through to hipMalloc, which waits
+    // for the running fills (9 ms inside a 13 ms call)
+    size_t g = 4096;
+    if (n >= ((size_t)1 << 20)) {
+        size_t p2 = (size_t)1 << 20;
+        while (p2 * 2 <= n) p2 *= 2;
+        g = std::max<size_t>((size_t)1 << 20, p2 / 8);
+    }
     return (n + g - 1) / g * g;
 }
 
@@ -248,6 +290,7 @@ int DevBuf::alloc(agx_ctx *c, size_t n)
     }
     if (!hit) {
         b.bytes = round_block(n);
+        if (agx_tune("AGX_TRACE_POOL")) fprintf(stderr, "[pool] device miss: %zu bytes asked, hipMalloc(%zu)\n", n, b.bytes);
         hipError_t e = hipMalloc(&b.p, b.bytes);
         if (e != hipSuccess) { // give the cache back and try once more
             std::vector<PoolBlock> drop;
@@ -307,6 +350,7 @@ int PinBuf::alloc(agx_ctx *c, size_t n)
     }
     if (!hit) {
         b.bytes = round_block(n);
+        if (agx_tune("AGX_TRACE_POOL")) fprintf(stderr, "[pool] pinned miss: %zu bytes asked, hipHostMalloc(%zu)\n", n, b.bytes);
         hipError_t e = hipHostMalloc(&b.p, b.bytes, hipHostMallocDefault);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -387,7 +431,7 @@ int agx_ctx_prepare_fanout(agx_ctx *c)
 int agx_ctx_prepare_plan(agx_ctx *c)
 {
     if (c->plan) return AGX_OK;
-    AGX_HIP(hipStreamCreateWithFlags(&c->plan, hipStreamNonBlocking));
+    AGX_HIP(hipStreamCreateWithPriority(&c->plan, hipStreamNonBlocking, c->prio_hi));
     AGX_HIP(hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming));
     return AGX_OK;
 }
@@ -533,7 +577,19 @@ int agx_ctx_create(int device, agx_ctx **out)
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) c->n_cu = cus;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) c->own_stream = true;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+    // The copy stream (uploads, the pack kernel) and the planning stream get the highest priority the device offers:
+    // their short kernels run beside the previous batch's fill, whose thousands of queued waves would otherwise keep
+    // them waiting for slots (a 0.16 ms pack kernel took 0.5 ms beside a fill).
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    c->prio_hi = prio_hi;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prio_hi);
+    // The planning stream is made here too, right behind the other two: the runtime multiplexes streams onto a few
+    // hardware queues in the order they are created, and a context's three streams must not share one -- made lazily,
+    // after another context's streams, `plan` landed on the queue of `copy` and every pack kernel waited for the next
+    // piece's upload (profiles/r03n_timeline.log).
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->plan, hipStreamNonBlocking, prio_hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) {

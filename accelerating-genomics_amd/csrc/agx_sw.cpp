@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -252,11 +253,17 @@ struct agx_sw_batch {
     bool matrix = false;
     std::vector<ClassLaunch> launches;
     agx_sw_info info{};
+    // A batch created without the closing wait (the pieces of agx_sw_score): its upload, planning and pack kernels may
+    // still be running; the temporaries they use, the event a launch has to wait for and the symbol check's verdict
+    // are held here until finish_create().
+    struct SwPending *pending = nullptr;
 };
 
 namespace {
 int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matrix *matrix, const uint8_t *bases,
-                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out);
+                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out, bool defer = false);
+int finish_create(agx_sw_batch *b);
+void drop_pending(agx_sw_batch *b);
 }
 
 extern "C" {
@@ -265,6 +272,7 @@ void agx_sw_batch_destroy(agx_sw_batch *b)
 {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    drop_pending(b);
     b->img.release();
     b->groups.release();
     b->waves.release();
@@ -329,13 +337,74 @@ struct DevPlan {
     std::vector<uint32_t> hist; // pairs per (class, G) bucket
     size_t img_dw = 0;
     bool started = false;
+    hipEvent_t uploaded = nullptr; // recorded on the copy stream behind this batch's sequences
+    hipEvent_t done = nullptr; // recorded behind this batch's planning kernels (its own: two creates may be in flight on one context)
     void release()
     {
+        if (done) (void)hipEventDestroy(done);
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        done = uploaded = nullptr;
         for (PinBuf *x : {&h_len, &h_buckets, &h_padded}) x->release();
         for (DevBuf *x : {&d_len, &d_buckets, &d_padded, &keys_a, &keys_b, &vals_a, &vals_b, &wkeys_a, &wkeys_b, &wids_a, &wids_b, &waves_tmp, &temp})
             x->release();
     }
 };
+
+} // namespace
+
+// everything a create leaves behind while its device work is still in flight
+struct SwPending {
+    agx_ctx *ctx = nullptr;
+    DevBuf d_raw, d_off, d_code, d_flag;
+    PinBuf h_groups, h_waves, h_flag, h_dense, h_dense_off;
+    DevPlan dp;
+    hipStream_t tail = nullptr; // the stream the pack kernel and the verdict's copy were queued on
+    hipEvent_t ready = nullptr; // recorded behind them: what a launch waits for
+    bool device_plan = false, matrix = false;
+    ~SwPending()
+    {
+        // kernels may still read the temporaries when an error path (or a destroy without finish) gets here
+        if (ctx && dp.started && ctx->plan) (void)hipStreamSynchronize(ctx->plan);
+        if (tail) (void)hipStreamSynchronize(tail);
+        if (ready) (void)hipEventDestroy(ready);
+        dp.release();
+        for (DevBuf *x : {&d_raw, &d_off, &d_code, &d_flag}) x->release();
+        for (PinBuf *x : {&h_groups, &h_waves, &h_flag, &h_dense, &h_dense_off}) x->release();
+    }
+};
+
+namespace {
+
+void drop_pending(agx_sw_batch *b)
+{
+    delete b->pending;
+    b->pending = nullptr;
+}
+
+// the closing wait of a deferred create: the symbol check's verdict, the device planner's padded-cell count
+int finish_create(agx_sw_batch *b)
+{
+    SwPending *p = b->pending;
+    if (!p) return AGX_OK;
+    const hipError_t e = hipStreamSynchronize(p->tail);
+    int rc = AGX_OK;
+    if (e != hipSuccess) {
+        agx_set_error("agx_sw_batch_create: upload -> %s", hipGetErrorString(e));
+        rc = AGX_E_HIP;
+    } else {
+        if (p->device_plan) b->info.padded_cells = (int64_t) * (const unsigned long long *)p->dp.h_padded.p;
+        const uint32_t *flag = (const uint32_t *)p->h_flag.p;
+        if (flag && flag[0]) {
+            if (p->matrix)
+                agx_set_error("pair %u contains a byte outside the substitution matrix's alphabet", flag[1]);
+            else
+                agx_set_error("pair %u contains byte 0x00, which is reserved as the padding symbol", flag[1]);
+            rc = AGX_E_SYMBOL;
+        }
+    }
+    drop_pending(b);
+    return rc;
+}
 
 // the family-2 tiling table on the device, made on the context's first device-planned batch
 int ensure_device_table(agx_ctx *ctx, hipStream_t s)
@@ -373,7 +442,16 @@ int launch_device_plan(agx_ctx *ctx, DevPlan &dp, agx_sw_batch *b, uint32_t n_pa
 {
     hipStream_t ps = ctx->plan;
     agx_sw_plan_preload();
-    int rc = ensure_device_table(ctx, ps);
+    int rc;
+    {
+        static std::mutex once_per_context; // the table is made by whichever create comes first
+        std::lock_guard<std::mutex> l(once_per_context);
+        rc = ensure_device_table(ctx, ps);
+    }
+    if (!rc && (hipEventCreateWithFlags(&dp.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&dp.uploaded, hipEventDisableTiming) != hipSuccess)) {
+        agx_set_error("device planner: cannot create an event");
+        rc = AGX_E_HIP;
+    }
     const size_t pw = (size_t)n_pairs * sizeof(uint32_t), ww = std::max<size_t>(n_waves, 1) * sizeof(uint32_t);
     const size_t temp_bytes = agx_sw_plan_temp_bytes(n_pairs, (uint32_t)n_waves);
     if (!rc) rc = b->groups.alloc(ctx, std::max<size_t>(n_groups, 1) * sizeof(SwGroup2));
@@ -418,12 +496,12 @@ int launch_device_plan(agx_ctx *ctx, DevPlan &dp, agx_sw_batch *b, uint32_t n_pa
         return AGX_E_HIP;
     }
     AGX_HIP(hipMemcpyAsync(dp.h_padded.p, dp.d_padded.p, 8, hipMemcpyDeviceToHost, ps));
-    AGX_HIP(hipEventRecord(ctx->plan_done, ps));
+    AGX_HIP(hipEventRecord(dp.done, ps));
     return AGX_OK;
 }
 
 int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matrix *matrix, const uint8_t *bases,
-                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out)
+                 const uint64_t *off, const uint32_t *len, int64_t n_pairs, agx_sw_batch **out, bool defer)
 {
     if (!out) {
         agx_set_error("agx_sw_batch_create: out is NULL");
@@ -676,17 +754,11 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
 
     // ---- the caller's arrays start travelling now, while the plan is made: a helper thread drives the
     // copies (a pageable source makes hipMemcpyAsync block while the runtime stages it)
-    DevBuf d_raw, d_off, d_code, d_flag;
-    PinBuf h_groups, h_waves, h_flag, h_dense, h_dense_off;
-    struct Temps {
-        DevBuf *d[4];
-        PinBuf *h[5];
-        ~Temps()
-        {
-            for (DevBuf *x : d) x->release();
-            for (PinBuf *x : h) x->release();
-        }
-    } temps{{&d_raw, &d_off, &d_code, &d_flag}, {&h_groups, &h_waves, &h_flag, &h_dense, &h_dense_off}};
+    std::unique_ptr<SwPending> tmp(new SwPending()); // released when this function leaves, or kept by the batch (defer)
+    tmp->ctx = ctx;
+    tmp->matrix = matrix != nullptr;
+    DevBuf &d_raw = tmp->d_raw, &d_off = tmp->d_off, &d_code = tmp->d_code, &d_flag = tmp->d_flag;
+    PinBuf &h_groups = tmp->h_groups, &h_waves = tmp->h_waves, &h_flag = tmp->h_flag, &h_dense = tmp->h_dense, &h_dense_off = tmp->h_dense_off;
     // `bases` is normally dense; a caller whose sequences are islands in a much larger array gets a dense
     // copy (pinned, its own offsets) instead of an upload of the gaps
     const bool dense_copy = (ext_hi - ext_lo) > 4 * sum_len + ((uint64_t)64 << 20);
@@ -747,11 +819,11 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
                     const int slot = k % kRing;
                     const size_t n = std::min(kSlice, (size_t)raw_bytes - at);
                     if (k >= kRing && hipEventSynchronize(done[slot]) != hipSuccess) r = AGX_E_HIP;
-                    const int parts = std::max(1, std::min(8, agx_host_threads())); // 4 copied 16 MB in 0.4 ms, above the slice's 0.29 ms DMA
+                    const int parts = std::max(1, agx_host_threads()); // every pool thread: 4 (round 2) and 8 copied a 16 MB slice in 0.4 ms, above its 0.29 ms DMA
                     const size_t per = (n + parts - 1) / parts;
                     agx_pool_run(parts, [&](int t) {
                         const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
-                        if (lo < hi) memcpy((uint8_t *)ring[slot].p + lo, src + at + lo, hi - lo);
+                        if (lo < hi) agx_stream_copy((uint8_t *)ring[slot].p + lo, src + at + lo, hi - lo);
                     });
                     if (!r && (hipMemcpyAsync((uint8_t *)d_raw.p + kRawPad + at, ring[slot].p, n, hipMemcpyHostToDevice, ctx->copy) != hipSuccess ||
                                hipEventRecord(done[slot], ctx->copy) != hipSuccess))
@@ -811,16 +883,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     // copies len[] into page-locked memory for its upload.  The rules that need another tiling (tail regime,
     // class consolidation, dominant shape) send the batch to the host planner.
     bool device_plan = false;
-    DevPlan dp;
-    struct DevPlanGuard { // kernels may still read the temporaries when an error path leaves
-        agx_ctx *c;
-        DevPlan &d;
-        ~DevPlanGuard()
-        {
-            if (d.started && c && c->plan) (void)hipStreamSynchronize(c->plan);
-            d.release();
-        }
-    } dp_guard{ctx, dp};
+    DevPlan &dp = tmp->dp;
     if (dev_candidate && family == 2 && !uniform && n_cu > 0 && n_fill > 0 && longest_short <= (uint32_t)kSwPackedMaxShort) {
         const TilingTable &tt = full_tiling_table(family);
         rc = dp.h_len.alloc(ctx, (size_t)n_pairs * 2 * sizeof(uint32_t));
@@ -1096,7 +1159,11 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (device_plan) {
         // ---- the buckets' extents from their counts (ascending bucket id = the sort order), then everything per pair on
         // the device, on the planning stream, beside the upload of the sequences
-        rc = agx_ctx_prepare_plan(ctx);
+        {
+            static std::mutex once_per_context;
+            std::lock_guard<std::mutex> l(once_per_context);
+            rc = agx_ctx_prepare_plan(ctx);
+        }
         if (!rc) rc = dp.h_buckets.alloc(ctx, (size_t)kSwPlanBuckets * 5 * sizeof(uint32_t));
         if (rc) return rc;
         uint32_t *bt = (uint32_t *)dp.h_buckets.p;
@@ -1319,15 +1386,21 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (rc) return rc;
     hipStream_t cs = ctx->copy;
     hipError_t e = hipSuccess;
-    if (device_plan) // the records are being written on the planning stream: the pack kernel comes behind them
-        e = hipStreamWaitEvent(cs, ctx->plan_done, 0);
+    // A device-planned batch packs on the PLANNING stream, behind its records, once its sequences have arrived (an event
+    // on the copy stream): the copy stream then carries nothing but uploads, and the next piece of a one-shot call
+    // (agx_sw_score: two creator threads) uploads right behind this one instead of behind this one's pack kernel.
+    hipStream_t ts = device_plan ? ctx->plan : cs;
+    if (device_plan) {
+        e = hipEventRecord(dp.uploaded, cs); // the uploader thread has queued everything (joined above)
+        if (e == hipSuccess) e = hipStreamWaitEvent(ts, dp.uploaded, 0);
+    }
     if (e == hipSuccess && !device_plan && groups_bytes) e = hipMemcpyAsync(b->groups.p, h_groups.p, groups_bytes, hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && !device_plan && waves_bytes) e = hipMemcpyAsync(b->waves.p, h_waves.p, waves_bytes, hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && matrix)
-        e = hipMemcpyAsync(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice, cs);
+        e = hipMemcpyAsync(b->table.p, table.data(), table.size() * sizeof(int16_t), hipMemcpyHostToDevice, ts);
     // pairs with an empty side are never touched by a kernel: their score is this zero
-    if (e == hipSuccess) e = hipMemsetAsync(b->scores.p, 0, b->scores.bytes, cs);
-    if (e == hipSuccess && packed) e = hipMemsetAsync(b->img.p, 0, (size_t)kSwPackedMaxShort + 4, cs);
+    if (e == hipSuccess) e = hipMemsetAsync(b->scores.p, 0, b->scores.bytes, ts);
+    if (e == hipSuccess && packed) e = hipMemsetAsync(b->img.p, 0, (size_t)kSwPackedMaxShort + 4, ts);
     uint32_t *flag = (uint32_t *)h_flag.p;
     flag[0] = 0;
     flag[1] = 0xffffffffu;
@@ -1338,17 +1411,29 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         const int pr = dna // the biased packed fill has a DNA-coded cell: its pack kernel decides per wavefront
                            ? agx_sw_pack_dna_launch((const uint8_t *)d_raw.p + kRawPad, (const uint64_t *)d_off.p, raw_base, b->groups.p, b->waves.p,
                                                     (uint32_t)n_waves_total, (uint32_t)n_pairs, (uint32_t *)b->img.p, (uint32_t *)d_flag.p,
-                                                    n_cu, cs)
+                                                    n_cu, ts)
                            : agx_sw_pack_launch(matrix != nullptr, slots, (const uint8_t *)d_raw.p + kRawPad, (const uint64_t *)d_off.p, raw_base,
                                                 b->groups.p, (uint32_t)n_groups, (uint32_t)n_pairs, (uint32_t *)b->img.p,
-                                                (const uint8_t *)d_code.p, (uint32_t *)d_flag.p, n_cu, cs);
+                                                (const uint8_t *)d_code.p, (uint32_t *)d_flag.p, n_cu, ts);
         if (pr) {
             agx_set_error("sw_pack launch failed: %s", hipGetErrorString(hipGetLastError()));
             return AGX_E_HIP;
         }
-        e = hipMemcpyAsync(flag, d_flag.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs);
+        e = hipMemcpyAsync(flag, d_flag.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ts);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(cs); // blocking by contract; the staging buffers are free again
+    if (e == hipSuccess && defer) { // the caller finishes later (finish_create): everything stays queued
+        e = hipEventCreateWithFlags(&tmp->ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(tmp->ready, ts);
+        if (e == hipSuccess) {
+            tmp->tail = ts;
+            tmp->device_plan = device_plan;
+            b->pending = tmp.release();
+            *out = b;
+            b = nullptr;
+            return AGX_OK;
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ts); // blocking by contract; the staging buffers are free again
     if (e != hipSuccess) {
         agx_set_error("agx_sw_batch_create: upload -> %s", hipGetErrorString(e));
         return AGX_E_HIP;
@@ -1388,6 +1473,8 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
+    // a batch whose create was not finished: its fill waits for the pack kernel on the device, not on the host
+    if (b->pending && b->pending->ready) AGX_HIP(hipStreamWaitEvent(b->ctx->stream, b->pending->ready, 0));
     FanOut fan(b->ctx, (int)b->launches.size());
     rc = fan.begin();
     if (rc) return rc;
@@ -1432,6 +1519,10 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
+    if (b->pending) { // (the pieces of agx_sw_score finish before they fetch; kept for safety)
+        rc = finish_create(b);
+        if (rc) return rc;
+    }
     if (b->n_pairs == 0) {
         AGX_HIP(hipStreamSynchronize(b->ctx->stream));
         return AGX_OK;
@@ -1499,16 +1590,32 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
         }
     } cleanup{bs};
     auto cut = [&](int k) { return n_pairs * k / pieces; };
-    for (int k = 0; k < pieces; ++k) {
-        const int64_t lo = cut(k), hi = cut(k + 1);
-        int rc = agx_sw_batch_create(ctx, bases, off + 2 * lo, len + 2 * lo, hi - lo, &bs[(size_t)k]);
-        if (rc == AGX_E_SYMBOL || rc == AGX_E_LIMIT) { // the messages name pair numbers: of the whole batch, not of the piece
+    // Every piece is created WITHOUT its closing wait and launched behind an event: the copy stream carries the pieces'
+    // uploads back to back, the planning stream their planning and pack kernels, the launch stream their fills, and
+    // the host is ahead of all three.  The verdicts of the symbol checks are collected afterwards, piece by piece (the
+    // first failing piece holds the smallest offending pair).
+    auto renumber = [&](int rc, int64_t lo) { // the messages name pair numbers: of the whole batch, not of the piece
+        if (rc == AGX_E_SYMBOL || rc == AGX_E_LIMIT) {
             unsigned long long p = 0;
             char rest[400] = "";
             if (sscanf(agx_last_error(), "pair %llu%399[^\n]", &p, rest) >= 1) agx_set_error("pair %llu%s", p + (unsigned long long)lo, rest);
         }
+        return rc;
+    };
+    const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
+    const double t_begin = now_ms();
+    for (int k = 0; k < pieces; ++k) {
+        const int64_t lo = cut(k), hi = cut(k + 1);
+        const double ta = now_ms();
+        int rc = renumber(create_batch(ctx, nullptr, nullptr, bases, off + 2 * lo, len + 2 * lo, hi - lo, &bs[(size_t)k], true), lo);
         if (!rc) rc = agx_sw_batch_launch(bs[(size_t)k]);
         if (rc) return rc;
+        if (trace) fprintf(stderr, "[agx_sw_score] piece %d of %d queued in %.2f ms (at %.2f)\n", k, pieces, now_ms() - ta, now_ms() - t_begin);
+    }
+    for (int k = 0; k < pieces; ++k) {
+        const int rc = renumber(finish_create(bs[(size_t)k]), cut(k));
+        if (rc) return rc;
+        if (trace) fprintf(stderr, "[agx_sw_score] piece %d finished at %.2f ms\n", k, now_ms() - t_begin);
     }
     for (int k = 0; k < pieces; ++k) {
         const int rc = agx_sw_batch_scores(bs[(size_t)k], scores + cut(k));
