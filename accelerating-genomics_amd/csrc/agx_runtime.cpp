@@ -582,6 +582,7 @@ int agx_ctx_create(int device, agx_ctx **out)
     // them waiting for slots (a 0.16 ms pack kernel took 0.5 ms beside a fill).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (agx_tune("AGX_NO_STREAM_PRIO")) prio_hi = 0; // A/B: every stream at the default priority
     c->prio_hi = prio_hi;
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->copy, hipStreamNonBlocking, prio_hi);
     // The planning stream is made here too, right behind the other two: the runtime multiplexes streams onto a few

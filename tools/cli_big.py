@@ -14,7 +14,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     f = os.path.join(d, "sw.in")
     t0 = time.perf_counter(); synth.write_sw_file(f, b); print("wrote %.0f MB in %.1f s" % (os.path.getsize(f) / 1e6, time.perf_counter() - t0), flush=True)
     want = ctx.sw_score(b)
-    for rep in range(3):
+    for rep in range(7):
         t0 = time.perf_counter()
         o = subprocess.run([os.path.join(BIN, "antidiagonalSmithWaterman"), f], stdout=open(os.path.join(d, "out.txt"), "wb"), stderr=subprocess.PIPE,
                            env=dict(os.environ, AGX_TRACE_CLI="1"))
@@ -27,11 +27,11 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     t0 = time.perf_counter(); synth.write_phmm_file(f, p); print("wrote %.0f MB in %.1f s" % (os.path.getsize(f) / 1e6, time.perf_counter() - t0), flush=True)
     want = ctx.phmm_forward(p, agx.PHMM_F64)
     for chunk in ("65536", "16384"):
-        for rep in range(2):
+        for rep in range(5):
             t0 = time.perf_counter()
             o = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), f, os.path.join(d, "p.out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                               env=dict(os.environ, AGX_CLI_CHUNK_PAIRS=chunk))
+                               env=dict(os.environ, AGX_CLI_CHUNK_PAIRS=chunk, AGX_TRACE_CLI="1"))
             dt = time.perf_counter() - t0
-            print("PairHMM CLI %d pairs (f64, chunks of %s pairs): wall %.3f s rc %d %s" % (p.n_pairs, chunk, dt, o.returncode, o.stderr.decode().strip()[:200]), flush=True)
+            print("PairHMM CLI %d pairs (f64, chunks of %s pairs): wall %.3f s rc %d %s" % (p.n_pairs, chunk, dt, o.returncode, o.stderr.decode().strip()[:400]), flush=True)
     got = np.array([float(x) for x in open(os.path.join(d, "p.out")).read().split()])
     print("PairHMM CLI output file == library call to 6 decimals:", bool(got.size == want.size and np.max(np.abs(got - want)) <= 5.1e-7), flush=True)

@@ -13,6 +13,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
             for _ in range(3):
                 t0 = time.perf_counter()
                 o = subprocess.run([os.path.join(BIN, "antidiagsPairHMM"), f, os.path.join(d, "p.out")], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                   env=dict(os.environ, AGX_CLI_CHUNK_PAIRS=chunk, AGX_PHMM_PRECISION=prec))
+                                   env=dict(os.environ, AGX_CLI_CHUNK_PAIRS=chunk, AGX_PHMM_PRECISION=prec, AGX_TRACE_CLI="1"))
                 ts.append(time.perf_counter() - t0)
-            print("PairHMM CLI 1048576 pairs %-6s chunks of %6s pairs: wall min %.3f median %.3f s rc %d" % (prec, chunk, min(ts), sorted(ts)[1], o.returncode), flush=True)
+            print("PairHMM CLI 1048576 pairs %-6s chunks of %6s pairs: wall min %.3f median %.3f max %.3f s rc %d | last run: %s" % (
+                prec, chunk, min(ts), sorted(ts)[1], max(ts), o.returncode, o.stderr.decode().strip()[-330:]), flush=True)
