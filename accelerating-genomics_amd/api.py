@@ -30,9 +30,9 @@ SYMBOLS = [
     "agx_version", "agx_last_error", "agx_device_count", "agx_device_name", "agx_ctx_create", "agx_ctx_destroy", "agx_ctx_device",
     "agx_ctx_stream", "agx_ctx_set_stream", "agx_ctx_sync", "agx_ctx_set_option", "agx_warmup_devices", "agx_host_alloc", "agx_host_free",
     "agx_ctx_timer_start", "agx_ctx_timer_stop", "agx_ctx_timer_mark", "agx_ctx_timer_elapsed",
-    "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
+    "agx_sw_batch_create", "agx_sw_batch_create_scored", "agx_sw_batch_create_matrix", "agx_sw_batch_launch", "agx_sw_batch_scores", "agx_sw_batch_bind_scores", "agx_sw_batch_info", "agx_sw_batch_destroy",
     "agx_sw_score", "agx_sw_score_multi", "agx_sw_score_devices", "agx_sw_shard_cuts",
-    "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_info",
+    "agx_phmm_batch_create", "agx_phmm_batch_launch", "agx_phmm_batch_results", "agx_phmm_batch_bind_results", "agx_phmm_batch_info",
     "agx_phmm_batch_destroy", "agx_phmm_forward", "agx_phmm_forward_multi", "agx_phmm_forward_devices", "agx_phmm_shard_cuts",
     "agx_pairHMM",
     "agx_sw_text_read", "agx_sw_text_free", "agx_sw_reader_open", "agx_sw_reader_line_num", "agx_sw_reader_set_threads", "agx_sw_reader_next",
@@ -141,6 +141,7 @@ def lib():
                                                  C.c_int64, C.POINTER(C.c_void_p)]
         l.agx_sw_batch_launch.argtypes = [C.c_void_p]
         l.agx_sw_batch_scores.argtypes = [C.c_void_p, C.c_void_p]
+        l.agx_sw_batch_bind_scores.argtypes = [C.c_void_p, C.c_void_p]
         l.agx_sw_batch_info.argtypes = [C.c_void_p, C.POINTER(SwInfo)]
         l.agx_sw_batch_destroy.argtypes = [C.c_void_p]
         l.agx_sw_batch_destroy.restype = None
@@ -154,6 +155,7 @@ def lib():
         l.agx_phmm_batch_launch.argtypes = [C.c_void_p]
         l.agx_phmm_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.agx_phmm_batch_info.argtypes = [C.c_void_p, C.POINTER(PhmmInfo)]
+        l.agx_phmm_batch_bind_results.argtypes = [C.c_void_p, C.c_void_p]
         l.agx_phmm_batch_destroy.argtypes = [C.c_void_p]
         l.agx_phmm_batch_destroy.restype = None
         l.agx_phmm_forward.argtypes = [C.c_void_p, C.POINTER(PhmmDesc), C.c_int, C.c_void_p]
@@ -292,6 +294,10 @@ class SwBatch:
         _check(lib().agx_sw_batch_scores(self._h, _ptr(out)))
         return out
 
+    def bind_scores(self, out):
+        """agx_sw_batch_bind_scores: out = a page-locked int32 array (host_array) or None."""
+        _check(lib().agx_sw_batch_bind_scores(self._h, _ptr(out) if out is not None else None))
+
     def info(self) -> SwInfo:
         i = SwInfo()
         _check(lib().agx_sw_batch_info(self._h, C.byref(i)))
@@ -341,6 +347,10 @@ class PhmmBatchDev:
             s = None
         _check(lib().agx_phmm_batch_results(self._h, _ptr(l), _ptr(s) if s is not None else None))
         return l, s
+
+    def bind_results(self, out):
+        """agx_phmm_batch_bind_results: out = a page-locked float64 array (host_array) or None."""
+        _check(lib().agx_phmm_batch_bind_results(self._h, _ptr(out) if out is not None else None))
 
     def info(self) -> PhmmInfo:
         i = PhmmInfo()

@@ -194,6 +194,7 @@ struct PlanOut {
     std::vector<PhWave> waves;
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
+    bool file_order = false; // one (R, H) shape: the records are in output order (agx_phmm_batch_bind_results)
 };
 
 // What a plan is made from: the pairs with work in output order (region, read, haplotype) and where the image holds
@@ -467,6 +468,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     // groups then have similar row counts, and haplotypes of one read stay adjacent (one LDS table).
     // `gen` is (read, haplotype)-ordered: two stable counting passes, by read length, then by class.
     std::vector<Plan> plan;
+    po.file_order = one_shape;
     if (one_shape)
         plan.swap(gen); // one (R, H) shape: one class, one G, equal keys throughout
     else {
@@ -663,6 +665,11 @@ struct agx_phmm_batch {
     DevBuf stripe_scratch;    // 6 * stripe_rows doubles per workgroup of the striped launch
     uint32_t stripe_rows = 0, stripe_grid = 0;
     agx_phmm_info info{};
+    // agx_phmm_batch_bind_results: a page-locked array of the caller's that a packed float fill in output order writes its
+    // log10 likelihoods into itself; bound_flag (in out_stage) says whether a pair went to the rescue plan instead
+    bool file_order = false;
+    double *bound = nullptr;
+    PinBuf bound_flag;
 };
 
 namespace {
@@ -940,6 +947,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     for (uint32_t r = 0; r < n_reads; ++r) longest_read = std::max<uint64_t>(longest_read, d->read_off[r + 1] - d->read_off[r]);
     const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && ph_lut_tab_bytes((uint32_t)longest_read + 2u) <= 40u * 1024u &&
                            !agx_tune("AGX_PHMM_NO_LUT");
+    const size_t n_work = gen0.size(); // pairs with work (every pair of the batch, unless a read or haplotype is empty)
     PlanOut pmain;
     rc = packed ? make_plan(seed, gen0, 3, 2, false, false, trace, pmain)
                 : make_plan(seed, std::move(gen0), precision, 1, f64, lut_prior, trace, pmain);
@@ -994,6 +1002,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->probs = probs;
     b->gatk_prior = gatk_prior;
     b->packed = packed;
+    b->file_order = packed && pmain.file_order && pstripe.waves.empty() && (int64_t)n_work == n_pairs;
     b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
     b->lut_prior = lut_prior;
     // the code objects this batch will launch from, loaded now rather than inside its first launch
@@ -1122,6 +1131,7 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     }
     b->sums.release();
     b->out_stage.release();
+    b->bound_flag.release();
     b->lut.release();
     b->counter.release();
     agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
@@ -1155,6 +1165,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     const bool f32_family = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
     if (f32_family) AGX_HIP(hipMemsetAsync(b->counter.p, 0, 2 * sizeof(unsigned long long), s));
     b->rescue_pending = b->separate_rescue;
+    if (b->bound) *(volatile unsigned *)b->bound_flag.p = 0; // set by the fill when a pair goes to the rescue plan
     const void *mis_for_d = b->gatk_prior ? mis_d : nullptr, *mis_for_f = b->gatk_prior ? mis_f : nullptr;
     auto launch_scalar = [&](const agx_phmm_batch::DevPlan &pl, const ClassLaunch &cl, int mode, hipStream_t st) -> int {
         const bool f64 = mode != 2;
@@ -1197,7 +1208,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                                                        (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
                                                        mis_for_f, (double *)b->sums.p,
                                                        PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1,
-                                                                   (double)(FLT_MAX / 16), (float)((b->gatk_prior ? kGuardGatk : kGuardRef) * 3.3219280948873623)},
+                                                                   (double)(FLT_MAX / 16), (float)((b->gatk_prior ? kGuardGatk : kGuardRef) * 3.3219280948873623),
+                                                                   b->bound, b->bound ? (unsigned *)b->bound_flag.p : nullptr, log10((double)(FLT_MAX / 16))},
                                                        cl.lds, st);
                 if (r) {
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
@@ -1310,6 +1322,16 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     }
     int rc = agx_bind(b->ctx);
     if (rc) return rc;
+    if (b->bound && log10_lik == b->bound && !raw_sum) {
+        // bound results: the fill wrote them into this array itself; only a pair sent to the rescue plan (underflow,
+        // accuracy guard) makes the long way below necessary
+        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+        if (*(volatile unsigned *)b->bound_flag.p == 0) {
+            b->rescue_pending = false;
+            b->info.n_rescued = 0;
+            return AGX_OK;
+        }
+    }
     // through pinned staging on the launch stream: the DMAs queue right behind the last kernel
     const size_t sum_bytes = (size_t)b->n_pairs * sizeof(double);
     const bool f32 = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
@@ -1367,6 +1389,33 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
     }
     return AGX_OK;
     AGX_GUARD_END("agx_phmm_batch_results")
+}
+
+int agx_phmm_batch_bind_results(agx_phmm_batch *b, double *log10_lik)
+{
+    if (!b) {
+        agx_set_error("agx_phmm_batch_bind_results: null batch");
+        return AGX_E_ARG;
+    }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device)");
+        return AGX_E_NODEVICE;
+    }
+    if (log10_lik && !agx_is_pinned_host(log10_lik, (size_t)std::max<int64_t>(b->n_pairs, 1) * sizeof(double))) {
+        agx_set_error("agx_phmm_batch_bind_results: the array is not page-locked memory of agx_host_alloc (or too short for %lld results)", (long long)b->n_pairs);
+        return AGX_E_ARG;
+    }
+    int rc = agx_bind(b->ctx);
+    if (rc) return rc;
+    AGX_HIP(hipStreamSynchronize(b->ctx->stream)); // launches in flight still write the old destination
+    // taken by packed float batches whose records are in output order (one (R, H) shape, every pair with work); a hint otherwise
+    const bool take = log10_lik && b->packed && b->file_order && b->n_pairs > 0;
+    if (take && !b->bound_flag.p) {
+        rc = b->bound_flag.alloc(b->ctx, 64);
+        if (rc) return rc;
+    }
+    b->bound = take ? log10_lik : nullptr;
+    return AGX_OK;
 }
 
 int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info)

@@ -106,6 +106,11 @@ struct PhUnderflow {
     unsigned long long *count;
     double guard_c;
     float guard_k2;
+    // agx_phmm_batch_bind_results: where the fill itself writes log10(sum) - log10(FLT_MAX / 16) (page-locked host memory,
+    // n_pairs doubles; NULL: nowhere), and a word it sets when a pair went to the rescue plan instead
+    double *logs_host;
+    unsigned *flag_host;
+    double log_c32;
 };
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,

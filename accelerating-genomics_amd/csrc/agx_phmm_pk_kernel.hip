@@ -342,6 +342,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             part_b += vb;
         }
     }
+    unsigned under = 0;
     if (active && gl == G - 1) {
         if (uf.guard_k2 != 0.0f) { // accuracy guard: a likelihood this close to 1 for a read this long goes to the double pass
             // (the hardware's own v_sqrt_f32 / v_exp_f32: three instructions; the library calls cost 2 % of the launch)
@@ -353,8 +354,24 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
         sums[g.out[1]] = part_b; // a group without a second haplotype points this at the spare slot
         // the census the host reads with the results: any pair below the float range means the double rescue plan
         // has to run (it is launched only then -- agx_phmm_batch_results)
-        const unsigned under = (unsigned)(!(part_a >= uf.below) && g.out[0] < uf.n_pairs) + (unsigned)(!(part_b >= uf.below) && g.out[1] < uf.n_pairs);
+        under = (unsigned)(!(part_a >= uf.below) && g.out[0] < uf.n_pairs) + (unsigned)(!(part_b >= uf.below) && g.out[1] < uf.n_pairs);
         if (under) atomicAdd(uf.count, (unsigned long long)under);
+    }
+    if (uf.logs_host) {
+        // Bound results (agx_phmm_batch_bind_results): the last line of pairHMM() -- log10(sum) - log10(C), :242 -- here, and
+        // straight into the caller's page-locked array.  The wave's results move to its first lanes (lane i takes group i's
+        // values from that group's last lane) so that neighbouring haplotypes leave as adjacent stores: one PCIe write per
+        // wave in a batch planned in output order.  A pair that went to the rescue plan sets the flag: the
+        // host then takes the results the long way (rescue pass, log10 kernel).
+        // lane j takes value j & 1 of group j >> 1 (from that group's last lane): ONE log10 per lane, and neighbouring
+        // haplotypes leave as adjacent 8-byte stores of adjacent lanes
+        const int src = (((lane >> 1) + 1) * G - 1) & 63;
+        const double pa = __shfl(part_a, src), pb = __shfl(part_b, src);
+        const uint32_t oa = (uint32_t)__shfl((int)g.out[0], src), ob = (uint32_t)__shfl((int)g.out[1], src);
+        const double v = (lane & 1) ? pb : pa;
+        const uint32_t o = (lane & 1) ? ob : oa;
+        if ((lane >> 1) < (int)w.n_groups && o < uf.n_pairs) uf.logs_host[o] = log10(v) - uf.log_c32;
+        if (under) *uf.flag_host = 1u;
     }
 }
 

@@ -257,6 +257,10 @@ struct agx_sw_batch {
     // still be running; the temporaries they use, the event a launch has to wait for and the symbol check's verdict
     // are held here until finish_create().
     struct SwPending *pending = nullptr;
+    // agx_sw_batch_bind_scores: a page-locked array of the caller's that launches write their scores into themselves
+    // (only a batch planned in file order does: its waves then write consecutive bytes)
+    bool file_order = false;
+    int32_t *bound = nullptr;
 };
 
 namespace {
@@ -751,6 +755,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     }
     b->matrix = matrix != nullptr;
     b->prm = prm;
+    b->prm.n_out = (uint32_t)n_pairs + 1u;
 
     // ---- the caller's arrays start travelling now, while the plan is made: a helper thread drives the
     // copies (a pageable source makes hipMemcpyAsync block while the runtime stages it)
@@ -990,6 +995,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             });
             plan.swap(all);
             planned = true;
+            b->file_order = true;
         }
     }
     double t_plan = now_ms(), t_sort = t_plan;
@@ -1475,6 +1481,8 @@ int agx_sw_batch_launch(agx_sw_batch *b)
     if (rc) return rc;
     // a batch whose create was not finished: its fill waits for the pack kernel on the device, not on the host
     if (b->pending && b->pending->ready) AGX_HIP(hipStreamWaitEvent(b->ctx->stream, b->pending->ready, 0));
+    SwParams prm = b->prm;
+    if (b->bound) prm.n_out = (uint32_t)b->n_pairs; // the caller's array has no spare slot
     FanOut fan(b->ctx, (int)b->launches.size());
     rc = fan.begin();
     if (rc) return rc;
@@ -1485,19 +1493,19 @@ int agx_sw_batch_launch(agx_sw_batch *b)
         hipStream_t st = fan.stream(k++);
         const uint32_t *img = (const uint32_t *)b->img.p;
         const SwWave *wv = (const SwWave *)b->waves.p + cl.first_wave;
-        int32_t *scores = (int32_t *)b->scores.p;
+        int32_t *scores = b->bound ? b->bound : (int32_t *)b->scores.p;
         int r;
         if (b->matrix)
-            r = agx_sw_mat_launch_class(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
+            r = agx_sw_mat_launch_class(cl.C, prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
                                         (const int16_t *)b->table.p, st);
         else if (b->family == 2 && cl.C == 0)
-            r = agx_sw_pk2_launch_any(b->rising, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+            r = agx_sw_pk2_launch_any(b->rising, prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 2)
-            r = agx_sw_pk2_launch_class(cl.C, b->rising, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+            r = agx_sw_pk2_launch_class(cl.C, b->rising, prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 1)
-            r = agx_sw_pk_launch_class(cl.C, b->prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
+            r = agx_sw_pk_launch_class(cl.C, prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else
-            r = (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(cl.C, b->prm, img, (const SwGroup *)b->groups.p, wv,
+            r = (cl.C > 40 ? agx_sw_wide_launch_class : agx_sw_launch_class)(cl.C, prm, img, (const SwGroup *)b->groups.p, wv,
                                                                              cl.n_waves, scores, st);
         if (r) {
             agx_set_error("sw_fill<%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
@@ -1528,6 +1536,15 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
         return AGX_OK;
     }
     const size_t bytes = (size_t)b->n_pairs * sizeof(int32_t);
+    if (b->bound && scores == b->bound) { // the launches wrote them there themselves: nothing to copy
+        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+        return AGX_OK;
+    }
+    if (b->bound) { // bound elsewhere: the device array was not written by the last launch
+        AGX_HIP(hipStreamSynchronize(b->ctx->stream));
+        memcpy(scores, b->bound, bytes);
+        return AGX_OK;
+    }
     // one copy kernel right behind the last fill on the launch stream: straight into the caller's array when that is
     // page-locked (agx_host_alloc), else into pinned staging and a host copy from there
     int32_t *dst = agx_is_pinned_host(scores, bytes) ? scores : (int32_t *)b->out_stage.p;
@@ -1537,6 +1554,29 @@ int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores)
     }
     AGX_HIP(hipStreamSynchronize(b->ctx->stream));
     if (dst != scores) memcpy(scores, dst, bytes);
+    return AGX_OK;
+}
+
+int agx_sw_batch_bind_scores(agx_sw_batch *b, int32_t *scores)
+{
+    if (!b) {
+        agx_set_error("agx_sw_batch_bind_scores: null batch");
+        return AGX_E_ARG;
+    }
+    if (!b->ctx) {
+        agx_set_error("this batch was planned without a context (no device)");
+        return AGX_E_NODEVICE;
+    }
+    if (scores && !agx_is_pinned_host(scores, (size_t)std::max<int64_t>(b->n_pairs, 1) * sizeof(int32_t))) {
+        agx_set_error("agx_sw_batch_bind_scores: the array is not page-locked memory of agx_host_alloc (or too short for %lld scores)", (long long)b->n_pairs);
+        return AGX_E_ARG;
+    }
+    const int rc = agx_bind(b->ctx);
+    if (rc) return rc;
+    AGX_HIP(hipStreamSynchronize(b->ctx->stream)); // launches in flight still write the old destination
+    // only a batch whose records are in file order takes the binding (a sorted batch's waves would scatter 4-byte
+    // writes over PCIe: measured slower than the copy kernel behind the fill); the call is a hint otherwise
+    b->bound = (scores && b->file_order && b->n_pairs > 0 && !b->matrix) ? scores : nullptr;
     return AGX_OK;
 }
 

@@ -28,6 +28,9 @@ struct SwParams {
     uint32_t ge2, gf2, hd2, delta2;
     // biased packed kernel (agx_sw_pk2_kernel.hip): |ge|, |gf| and the bias B added to every stored half
     uint32_t age2, agf2, bias2;
+    // slots of the scores array a launch may write (packed kernels: a vacant half points at slot n_pairs, which exists in
+    // the device array but not in a caller's page-locked one -- agx_sw_batch_bind_scores)
+    uint32_t n_out;
 };
 
 // Packed kernel: one group of G lanes carries two pairs (index 0 = low 16 bits, 1 = high 16 bits

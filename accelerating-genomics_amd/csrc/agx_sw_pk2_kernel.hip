@@ -363,10 +363,24 @@ __device__ __forceinline__ void pk2_fill(const SwParams &prm, const uint32_t *__
         const uint32_t other = (uint32_t)__shfl_down((int)bestv, o);
         if (gl + o < G) bestv = umax2(bestv, other);
     }
-    if (feeder) {
+    {
         const int off = (int)(z0 & 0xffffu) + (RISE ? (steps + 1) * (int)(prm.age2 & 0xffffu) : 0); // stored value of H = 0, at r(steps - 1)
-        scores[g.out[0]] = (int)(bestv & 0xffffu) - off;
-        scores[g.out[1]] = (int)(bestv >> 16) - off; // a group without a second pair points this at the spare slot
+        // The wave's results move to its first lanes -- lane i takes group i's two scores from that group's first lane --
+        // and go out from there: neighbouring pairs as ONE 8-byte store per group, so that in a batch planned in file order
+        // adjacent lanes write adjacent bytes and the wave's scores leave as one request (one PCIe write when the scores
+        // array is the caller's page-locked one, agx_sw_batch_bind_scores; the spare slot n_pairs a vacant half points at
+        // does not exist there).
+        const int src = (lane * G) & 63;
+        const int sa = __shfl((int)(bestv & 0xffffu) - off, src), sb = __shfl((int)(bestv >> 16) - off, src);
+        const uint32_t oa = (uint32_t)__shfl((int)g.out[0], src), ob = (uint32_t)__shfl((int)g.out[1], src);
+        if (lane < (int)w.n_groups) {
+            if (ob == oa + 1u && !(oa & 1u) && ob < prm.n_out)
+                *reinterpret_cast<int2 *>(scores + oa) = make_int2(sa, sb);
+            else {
+                scores[oa] = sa;
+                if (ob < prm.n_out) scores[ob] = sb;
+            }
+        }
     }
 }
 

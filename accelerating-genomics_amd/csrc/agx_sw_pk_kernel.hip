@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) sw_fill_pk(const SwParams prm, const uint
     }
     if (feeder) {
         scores[g.out[0]] = (int)best[0] - prm.gf;
-        scores[g.out[1]] = (int)best[1] - prm.gf; // a group without a second pair points this at the spare slot
+        if (g.out[1] < prm.n_out) scores[g.out[1]] = (int)best[1] - prm.gf; // a group without a second pair points this at the spare slot
     }
 }
 

@@ -167,6 +167,11 @@ int agx_sw_batch_create_matrix(agx_ctx *ctx, const agx_sw_matrix *matrix, const 
 int agx_sw_batch_launch(agx_sw_batch *b);
 /* Wait for the stream and copy the scores out in the caller's pair order. */
 int agx_sw_batch_scores(agx_sw_batch *b, int32_t *scores);
+/* Optional: name the page-locked array (agx_host_alloc, n_pairs ints) the scores are wanted in BEFORE launching.  A batch
+ * whose records are in file order (a uniform batch: fixed-length reads) then lets every launch write its scores there
+ * itself -- one PCIe write per wavefront, no copy kernel behind the fill -- and agx_sw_batch_scores(b, the same pointer)
+ * only waits.  Other batches keep the copy; scores == NULL unbinds.  The array must stay valid while it is bound. */
+int agx_sw_batch_bind_scores(agx_sw_batch *b, int32_t *scores);
 int agx_sw_batch_info(const agx_sw_batch *b, agx_sw_info *info);
 void agx_sw_batch_destroy(agx_sw_batch *b);
 
@@ -245,6 +250,12 @@ int agx_phmm_batch_launch(agx_phmm_batch *b);
 /* log10_lik[k] = log10(sum_k) - log10(C), C = DBL_MAX/16 (FLT_MAX/16 for F32), both log10 taken by the
  * host libm in double exactly as antidiagsPairHMM.c:242; raw_sum (may be NULL) receives sum_k. */
 int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum);
+/* Optional, the PairHMM counterpart of agx_sw_batch_bind_scores: name the page-locked array (agx_host_alloc, n_pairs
+ * doubles) the log10 likelihoods are wanted in BEFORE launching.  An AGX_PHMM_F32_FMA batch in output order (one read and
+ * haplotype length throughout, every pair with work) then lets its fill compute log10(sum) - log10(C) and write it there
+ * itself -- no log10 kernel behind the fill -- and agx_phmm_batch_results(b, the same pointer, NULL) only waits, unless a
+ * pair went to the double rescue plan.  Other batches keep the usual path; NULL unbinds. */
+int agx_phmm_batch_bind_results(agx_phmm_batch *b, double *log10_lik);
 int agx_phmm_batch_info(const agx_phmm_batch *b, agx_phmm_info *info);
 void agx_phmm_batch_destroy(agx_phmm_batch *b);
 

@@ -458,3 +458,50 @@ def test_float_modes_hold_1e6_across_read_lengths(ctx, seed):
     dev.results()
     assert dev.info().n_rescued == 0
     dev.close()
+
+
+def test_bound_results_arrive_in_the_callers_page_locked_array(ctx, oracle):
+    """agx_phmm_batch_bind_results: a packed float batch in output order computes log10(sum) - log10(C) in its fill and
+    writes it into the caller's page-locked array; odd haplotype counts (vacant halves), pairs that go to the rescue plan
+    (the flag sends the host the long way), rebinding, a mixed batch and the double mode (both: a hint)."""
+    for haps in (16, 5):
+        p = synth.phmm_regions(6, 16, haps, 100, 300, seed=70 + haps)
+        _, ref = oracle.phmm_batch(p, 0)
+        dev = ctx.phmm_batch(p, agx.PHMM_F32_FMA)
+        out = agx.host_array(p.n_pairs + 4, np.float64)
+        out[:] = 7.0
+        dev.bind_results(out[:p.n_pairs])
+        for _ in range(2):
+            dev.launch()
+            got, _ = dev.results((out[:p.n_pairs], None), want_sums=False)
+            assert relerr(out[:p.n_pairs], ref) <= 1e-6 and np.all(out[p.n_pairs:] == 7.0) and dev.info().n_rescued == 0
+        plain = ctx.phmm_forward(p, agx.PHMM_F32_FMA)
+        assert np.array_equal(out[:p.n_pairs], plain)      # the fill's log10 is the log10 kernel's
+        other, sums = dev.results()                           # fetched elsewhere, with the sums: the usual path
+        assert np.array_equal(other, plain) and np.all(sums > 0)
+        dev.bind_results(None)
+        dev.launch()
+        assert np.array_equal(dev.results()[0], plain)
+        with pytest.raises(agx.AgxError):
+            dev.bind_results(np.empty(p.n_pairs, np.float64))
+        dev.close()
+    # unrelated reads underflow float: every pair is rescued in double, bound or not
+    far = synth.phmm_regions(2, 8, 4, 100, 300, seed=81)
+    far.read_bases[:] = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(82).integers(0, 4, far.read_bases.size)]
+    _, ref = oracle.phmm_batch(far, 0)
+    dev = ctx.phmm_batch(far, agx.PHMM_F32_FMA)
+    out = agx.host_array(far.n_pairs, np.float64)
+    dev.bind_results(out)
+    dev.launch()
+    dev.results((out, None), want_sums=False)
+    assert relerr(out, ref) <= 1e-6 and dev.info().n_rescued == far.n_pairs
+    dev.close()
+    for p, prec in ((synth.phmm_regions(4, 8, 4, 100, 300, seed=83, jitter=30), agx.PHMM_F32_FMA), (synth.phmm_regions(2, 8, 4, 100, 300, seed=84), agx.PHMM_F64)):
+        _, ref = oracle.phmm_batch(p, 0)
+        dev = ctx.phmm_batch(p, prec)
+        out = agx.host_array(p.n_pairs, np.float64)
+        dev.bind_results(out)                                 # a hint for these
+        dev.launch()
+        dev.results((out, None), want_sums=False)
+        assert relerr(out, ref) <= 1e-6
+        dev.close()

@@ -384,3 +384,42 @@ def test_one_shot_score_of_a_large_batch_runs_in_pieces(ctx, oracle):
     with pytest.raises(agx.AgxError) as e:
         ctx.sw_score(bad)
     assert e.value.code == agx.E_SYMBOL and "pair 250001 " in str(e.value)
+
+
+def test_bound_scores_arrive_in_the_callers_page_locked_array(ctx, oracle):
+    """agx_sw_batch_bind_scores: a batch planned in file order (uniform lengths) writes its scores into the caller's
+    page-locked array from the fill itself (8-byte stores, a wave's groups side by side); odd pair counts (the vacant
+    half's spare slot does not exist there), every kernel family, rebinding, and a sorted batch, for which the call is a
+    hint and the copy stays."""
+    for n in (4097, 20000):
+        b = synth.sw_pairs(n, 150, 150, seed=50 + n, related_frac=0.3)
+        want = oracle_api.sw_batch_mt(oracle, b)
+        for kernel in (agx.SW_KERNEL_AUTO, agx.SW_KERNEL_INT32, agx.SW_KERNEL_PACKED_SIGNED):
+            ctx.set_option(agx.OPT_SW_KERNEL, kernel)
+            try:
+                dev = ctx.sw_batch(b)
+            finally:
+                ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_AUTO)
+            out = agx.host_array(n + 8, np.int32)
+            out[:] = -7
+            dev.bind_scores(out[:n])
+            for _ in range(2):
+                dev.launch()
+                got = dev.scores(out[:n])
+                assert got is not None and np.array_equal(out[:n], want) and np.all(out[n:] == -7)  # nothing written behind the array
+            other = np.empty(n, np.int32)              # fetched elsewhere while bound: a copy of the bound array
+            dev.launch()
+            assert np.array_equal(dev.scores(other), want)
+            dev.bind_scores(None)                      # unbound: the device array and the copy kernel again
+            dev.launch()
+            assert np.array_equal(dev.scores(), want)
+            with pytest.raises(agx.AgxError):
+                dev.bind_scores(np.empty(n, np.int32))  # not page-locked
+            dev.close()
+    mixed = synth.sw_pairs(3000, 20, 300, seed=77)
+    dev = ctx.sw_batch(mixed)
+    out = agx.host_array(mixed.n_pairs, np.int32)
+    dev.bind_scores(out)                               # a hint here
+    dev.launch()
+    assert np.array_equal(dev.scores(out), oracle.sw_batch(mixed))
+    dev.close()
