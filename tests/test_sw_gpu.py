@@ -423,3 +423,35 @@ def test_bound_scores_arrive_in_the_callers_page_locked_array(ctx, oracle):
     dev.launch()
     assert np.array_equal(dev.scores(out), oracle.sw_batch(mixed))
     dev.close()
+
+
+def test_device_planned_batch_with_waves_of_every_kind(ctx, oracle):
+    """A large mixed batch whose waves are of every kind the pack kernel knows: plain DNA (coded), a fifth symbol in the
+    shorter sequence (bytes, general cell), a newline inside a sequence, a missing final newline, sequences of one and two
+    symbols, lengths up to the packed kernel's 2560 columns -- planned on the device, packed by 16-byte chunks, scored
+    bit-exactly."""
+    rng = np.random.default_rng(91)
+    b = synth.sw_pairs(70000, 1, 260, seed=92, related_frac=0.3)
+    long_ones = synth.sw_pairs(40, 1800, 2559, seed=93, related_frac=0.5)
+    bases = np.concatenate([b.bases, long_ones.bases])
+    off = np.concatenate([b.off, long_ones.off + np.uint64(b.bases.size)])
+    ln = np.concatenate([b.len, long_ones.len])
+    b = synth.SWBatch(bases, off, ln)
+    n = b.n_pairs
+    for p in rng.choice(n, size=n // 10, replace=False):          # an N somewhere in one sequence of the pair
+        k = 2 * int(p) + int(rng.integers(0, 2))
+        if b.len[k] > 1:
+            b.bases[int(b.off[k]) + int(rng.integers(0, int(b.len[k]) - 1))] = ord("N")
+    for p in rng.choice(n, size=300, replace=False):              # a newline inside / no final newline
+        k = 2 * int(p) + int(rng.integers(0, 2))
+        if b.len[k] > 2:
+            if rng.random() < 0.5:
+                b.bases[int(b.off[k]) + int(rng.integers(0, int(b.len[k]) - 1))] = 10
+            else:
+                b.bases[int(b.off[k]) + int(b.len[k]) - 1] = ord("A")
+    s_dev, i_dev = _planned(ctx, b, agx.SW_PLANNER_DEVICE)
+    assert i_dev.planned_on_device == 1
+    sub = np.concatenate([np.arange(0, 70000, 9), np.arange(70000, n)])
+    assert np.array_equal(s_dev[sub], oracle_api.sw_batch_mt(oracle, b.subset(sub)))
+    s_host, i_host = _planned(ctx, b, agx.SW_PLANNER_HOST)
+    assert np.array_equal(s_host, s_dev) and i_host.padded_cells == i_dev.padded_cells and i_host.n_waves == i_dev.n_waves
