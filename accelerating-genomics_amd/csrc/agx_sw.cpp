@@ -79,9 +79,9 @@ int tuned_kernel() // 0 = no override
 }
 
 // per-class cost table of the kernel family a batch runs (relative lane time per padded cell)
-inline const double *class_costs(int family) // 0 int32, 1 packed signed, 2 packed biased
+inline const double *class_costs(int family) // 0 int32, 1 packed signed, 2 packed biased, 3 int32 on the packed plan's coded image
 {
-    return family == 0 ? kSwClassCost : family == 1 ? kSwPkClassCost : kSwPk2ClassCost;
+    return family == 0 ? kSwClassCost : family == 1 ? kSwPkClassCost : family == 3 ? kSwI32dClassCost : kSwPk2ClassCost;
 }
 
 // Lane time a pair costs under tiling (class ci, G): steps * C * 64 / floor(64 / G) padded cells (the
@@ -242,7 +242,7 @@ inline double now_ms()
 
 struct agx_sw_batch {
     agx_ctx *ctx = nullptr; // retained
-    int family = 0;         // 0 int32, 1 packed signed, 2 packed biased
+    int family = 0;         // 0 int32, 1 packed signed, 2 packed biased, 3 int32 on the packed plan's coded image
     SwParams prm{};
     int64_t n_pairs = 0;
     DevBuf img, groups, waves, scores;
@@ -325,8 +325,8 @@ constexpr int64_t kDevPlanMinPairs = 49152;
 // family's limit): what a device-planned batch is tiled with.  Made once per process.
 const TilingTable &full_tiling_table(int family)
 {
-    static TilingTable tabs[3];
-    static std::once_flag once[3];
+    static TilingTable tabs[4];
+    static std::once_flag once[4];
     std::call_once(once[family], [family] {
         const std::vector<uint8_t> present((size_t)(family == 0 ? AGX_SW_MAX_SHORT_LEN : kSwPackedMaxShort) + 1, 1);
         build_tiling_table(tabs[family], present, class_costs(family), ~0u, 0.0);
@@ -694,6 +694,10 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     // [0x0400, 0x7c00): smallest B - max(|gf| + |ge|, delta), largest B + (longest shorter side + 1) * match + |gf|.
     int family = want == AGX_SW_KERNEL_INT32 ? 0 : want == AGX_SW_KERNEL_PACKED_SIGNED ? 1 : 2;
     if (matrix || longest_short > (uint32_t)kSwPackedMaxShort) family = 0; // the matrix lookup exists in the int32 kernel only
+    // The int32 kernel asked for (BASELINE config 2 as worded) runs the packed plan and its DNA-coded image in 32-bit state,
+    // one pair of a lane group at a time (agx_sw_i32d_kernel.hip: 7.5 instead of 8.5 instructions per cell), wherever the
+    // coded match exists: delta and mismatch + |gf| must be bytes, the shorter sides within the packed plan's 2560 columns.
+    if (family == 0 && !matrix && longest_short <= (uint32_t)kSwPackedMaxShort && prm.delta < 128 && prm.hd >= prm.delta && !agx_tune("AGX_SW_I32_CLASSIC")) family = 3;
     if (family == 2 && !((int64_t)bias + ((int64_t)longest_short + 1) * sc.match - prm.gf < 0x7c00)) family = 1;
     // ... and its rising-offset variant adds (steps + 2) |ge| on top, steps <= longest longer side + 63
     int rising = family == 2 &&
@@ -751,6 +755,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         agx_sw_pack_preload();
         agx_copy_preload();
         if (family == 2) agx_sw_pk2_preload();
+        if (family == 3) agx_sw_i32d_preload();
         if (family == 0 && !matrix) agx_sw_i32_preload();
     }
     b->matrix = matrix != nullptr;
@@ -1056,7 +1061,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         // (the biased packed fill runs two waves per SIMD, and with its round-2b cell the term pays up to 1.2 of ITS
         // fillings = 0.48 of these: 45 056 mixed pairs 6.5 -> 7.2 TCUPS, 49 152 7.15 -> 7.26, but 57 344 7.74 -> 7.55 and
         // 65 536 8.07 -> 7.71 -- tools/sw_tail_rule_check.py)
-        if (fill < (family == 2 ? 0.48 : 1.6)) {
+        if (fill < (family >= 2 ? 0.48 : 1.6)) {
             beta_used = fill < 0.1 ? 10.0 : fill < 0.4 ? 6.0 : 3.0;
             tile_all(~0u, beta_used, false);
         }
@@ -1082,7 +1087,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         // 5.48 -> 5.81.  Smaller batches are in the tail regime, where the launch lasts as long as its longest
         // waves and the few-classes rule still wins (16 384 pairs: 3.58 against 3.02 TCUPS; tools/sw_mixed_check.py).
         const int k_max = max_classes_override()                  ? std::min(max_classes_override(), 1 + (int)(waves_est / per_class))
-                          : family == 2 && waves_est >= 2048.0 ? kSwNumClasses
+                          : family >= 2 && waves_est >= 2048.0 ? kSwNumClasses
                                                                   : std::min(6, 1 + (int)(waves_est / per_class));
         int used = 0;
         for (int c = 0; c < kSwNumClasses; ++c) used += work[c] > 0;
@@ -1264,7 +1269,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
         const char *e = agx_tune("AGX_SW_ONE_LAUNCH");
         return !(e && e[0] == '0');
     }();
-    if (family == 2 && launches.size() > 1 && one_launch_ok) {
+    if (family >= 2 && launches.size() > 1 && one_launch_ok) {
         if (sort_waves)
             std::stable_sort(waves.begin(), waves.end(), [](const SwWave &a, const SwWave &b) {
                 return (uint64_t)a.steps * a.reserved > (uint64_t)b.steps * b.reserved;
@@ -1413,7 +1418,7 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
     if (e == hipSuccess && n_groups) {
         const char *dna_knob = agx_tune("AGX_SW_DNA");
         // the DNA-coded cell adds (mismatch + |gf|) and a table byte: both must be non-negative bytes
-        const bool dna = family == 2 && prm.delta < 128 && prm.hd >= prm.delta && !(dna_knob && dna_knob[0] == '0');
+        const bool dna = family >= 2 && prm.delta < 128 && prm.hd >= prm.delta && !(dna_knob && dna_knob[0] == '0');
         const int pr = dna // the biased packed fill has a DNA-coded cell: its pack kernel decides per wavefront
                            ? agx_sw_pack_dna_launch((const uint8_t *)d_raw.p + kRawPad, (const uint64_t *)d_off.p, raw_base, b->groups.p, b->waves.p,
                                                     (uint32_t)n_waves_total, (uint32_t)n_pairs, (uint32_t *)b->img.p, (uint32_t *)d_flag.p,
@@ -1498,6 +1503,9 @@ int agx_sw_batch_launch(agx_sw_batch *b)
         if (b->matrix)
             r = agx_sw_mat_launch_class(cl.C, prm, img, (const SwGroup *)b->groups.p, wv, cl.n_waves, scores,
                                         (const int16_t *)b->table.p, st);
+        else if (b->family == 3)
+            r = cl.C == 0 ? agx_sw_i32d_launch_any(prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st)
+                          : agx_sw_i32d_launch_class(cl.C, prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 2 && cl.C == 0)
             r = agx_sw_pk2_launch_any(b->rising, prm, img, (const SwGroup2 *)b->groups.p, wv, cl.n_waves, scores, st);
         else if (b->family == 2)

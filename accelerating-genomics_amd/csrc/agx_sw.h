@@ -73,6 +73,9 @@ static const double kSwPkClassCost[] = {1.543, 1.358, 1.278, 1.210, 1.173, 1.136
 // profiles/r02h_cal_sw_pk2.log: 0.0951 ps per padded cell at 40 columns)
 static const double kSwPk2ClassCost[] = {1.851, 1.581, 1.450, 1.367, 1.318, 1.263, 1.196, 1.184, 1.145, 1.097, 1.095, 1.056, 1.049, 1.053, 1.025, 1.023, 1.022, 1.016, 1.000, 0, 0, 0};
 
+// the 32-bit fill on the packed plan's coded image (agx_sw_i32d_kernel.hip): the int32 kernel's per-class costs, no wide classes
+static const double kSwI32dClassCost[] = {1.373, 1.250, 1.178, 1.138, 1.112, 1.080, 1.051, 1.033, 1.025, 1.022, 1.014, 1.014, 1.011, 1.007, 1.007, 1.004, 1.004, 1.004, 1.000, 0, 0, 0};
+
 // substitution-matrix mode: symbol numbers 1..32 in the image, 0 = padding; the device table is
 // kSwMatDim x kSwMatDim int16 entries score - (gap_open + gap_extend)
 constexpr int kSwMatDim = 33;
@@ -98,6 +101,12 @@ void agx_sw_pack_preload();
 void agx_sw_i32_preload();
 int agx_sw_pk2_launch_any(int rising, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves,
                           int32_t *scores, hipStream_t s);
+// the 32-bit fill with the DNA-coded match: the packed plan's records and image, one pair of a lane group at a time
+int agx_sw_i32d_launch_any(const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves, uint32_t n_waves, int32_t *scores,
+                           hipStream_t s);
+int agx_sw_i32d_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup2 *groups, const SwWave *waves,
+                             uint32_t n_waves, int32_t *scores, hipStream_t s);
+void agx_sw_i32d_preload();
 int agx_sw_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,
                         const SwWave *waves, uint32_t n_waves, int32_t *scores, hipStream_t s);
 int agx_sw_wide_launch_class(int cols_per_lane, const SwParams &prm, const uint32_t *img, const SwGroup *groups,

@@ -606,7 +606,7 @@ def main():
                "valu": {"ops_per_cell": "6.75 instructions per 2 cells (DNA-coded rising cell with column classes): v_pk_maximum3_f16 x2.5, v_pk_max_u16, v_perm_b32, v_add3_u32, v_sub_u32 x1.25",
                         "frac_of_instruction_mix_ceiling": sw_info.padded_cells * (6.75 / 2 / VALU_PACKED) / (sw_t["launch_ms"] * 1e-3)},
                "score_checksum": sw_sum},
-        "sw_int32": dict(i32_leg, metric="config 2 through the int32 kernel (one pair per lane group, AGX_SW_KERNEL_INT32)", unit="GCUPS",
+        "sw_int32": dict(i32_leg, metric="config 2 through the int32 kernel (AGX_SW_KERNEL_INT32: 32-bit state, one pair at a time per lane group, DNA-coded match: 7.5 instructions per cell)", unit="GCUPS",
                          scores_identical_to_packed=i32_same, useful_cell_fraction=i32_info.cells / max(1, i32_info.padded_cells),
                          roofline=roof(sw.algorithmic_bytes(), i32_t["launch_ms"], "sw_fill_int32")),
         "pairhmm": dict(ph_leg, metric="PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)", unit="pairs/s",

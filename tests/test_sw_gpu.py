@@ -431,7 +431,7 @@ def test_device_planned_batch_with_waves_of_every_kind(ctx, oracle):
     symbols, lengths up to the packed kernel's 2560 columns -- planned on the device, packed by 16-byte chunks, scored
     bit-exactly."""
     rng = np.random.default_rng(91)
-    b = synth.sw_pairs(70000, 1, 260, seed=92, related_frac=0.3)
+    b = synth.sw_pairs(130000, 1, 260, seed=92, related_frac=0.3)
     long_ones = synth.sw_pairs(40, 1800, 2559, seed=93, related_frac=0.5)
     bases = np.concatenate([b.bases, long_ones.bases])
     off = np.concatenate([b.off, long_ones.off + np.uint64(b.bases.size)])
@@ -451,7 +451,7 @@ def test_device_planned_batch_with_waves_of_every_kind(ctx, oracle):
                 b.bases[int(b.off[k]) + int(b.len[k]) - 1] = ord("A")
     s_dev, i_dev = _planned(ctx, b, agx.SW_PLANNER_DEVICE)
     assert i_dev.planned_on_device == 1
-    sub = np.concatenate([np.arange(0, 70000, 9), np.arange(70000, n)])
+    sub = np.concatenate([np.arange(0, 130000, 17), np.arange(130000, n)])
     assert np.array_equal(s_dev[sub], oracle_api.sw_batch_mt(oracle, b.subset(sub)))
     s_host, i_host = _planned(ctx, b, agx.SW_PLANNER_HOST)
     assert np.array_equal(s_host, s_dev) and i_host.padded_cells == i_dev.padded_cells and i_host.n_waves == i_dev.n_waves
