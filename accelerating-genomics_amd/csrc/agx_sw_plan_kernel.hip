@@ -8,7 +8,7 @@
 // sorts): tests/test_sw_gpu.py compares the two planners through agx_sw_batch_info and the scores.
 //
 //   sw_plan_keys     pair -> sort key (class << 22 | (64 - G) << 16 | longest - ly), value = pair number
-//   [radix sort]     hipcub::DeviceRadixSort::SortPairs, 28 bits, stable (pairs with an empty side sort last)
+//   [radix sort]     rocprim::radix_sort_pairs, 28 bits, stable (pairs with an empty side sort last)
 //   sw_plan_words    sorted entry -> words of its image block; [exclusive scan] -> image offsets
 //   sw_plan_records  sorted entry -> its half of a SwGroup2 / its SwGroup, the SwWave of the wave it opens,
 //                    that wave's dispatch key (longest first), padded cells
@@ -16,7 +16,9 @@
 //
 // The host gives the (class, G) buckets' extents -- it counts them in its reduction pass -- so nothing here needs a
 // round trip: every launch size is known before the first kernel runs.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "agx_sw.h"
 
@@ -127,11 +129,12 @@ inline uint32_t blocks_for(uint64_t n, int n_cu) { return (uint32_t)std::min<uin
 size_t agx_sw_plan_temp_bytes(uint32_t n_pairs, uint32_t n_waves)
 {
     size_t a = 0, b = 0, c = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (int)n_pairs, 0, 28, (hipStream_t) nullptr);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_pairs, (hipStream_t) nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, c, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                             (int)std::max(n_waves, 1u), 0, 24, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, a, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (size_t)n_pairs, 0u, 28u, (hipStream_t) nullptr);
+    (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, (size_t)n_pairs, rocprim::plus<uint32_t>(),
+                                  (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, c, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (size_t)std::max(n_waves, 1u), 0u, 24u, (hipStream_t) nullptr);
     return std::max(a, std::max(b, c)) + 256;
 }
 
@@ -141,13 +144,13 @@ int agx_sw_plan_launch(const SwPlanArgs &a, hipStream_t s)
     const uint32_t n = a.n_pairs;
     hipLaunchKernelGGL(sw_plan_keys, dim3(blocks_for(n, a.n_cu)), dim3(256), 0, s, a.len, n, a.seg_first, a.segs, a.longest, a.keys_a, a.vals_a);
     size_t tb = a.temp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(a.temp, tb, a.keys_a, a.keys_b, a.vals_a, a.vals_b, (int)n, 0, 28, s) != hipSuccess) return -1;
+    if (rocprim::radix_sort_pairs(a.temp, tb, a.keys_a, a.keys_b, a.vals_a, a.vals_b, (size_t)n, 0u, 28u, s) != hipSuccess) return -1;
     if (a.n_fill == 0) return hipGetLastError() == hipSuccess ? 0 : -1;
     // keys_a / vals_a are free again: words and their scan live there
     uint32_t *words = a.keys_a, *scan = a.vals_a;
     hipLaunchKernelGGL(sw_plan_words, dim3(blocks_for(a.n_fill, a.n_cu)), dim3(256), 0, s, a.keys_b, a.n_fill, a.longest, words);
     tb = a.temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(a.temp, tb, words, scan, (int)a.n_fill, s) != hipSuccess) return -1;
+    if (rocprim::exclusive_scan(a.temp, tb, words, scan, 0u, (size_t)a.n_fill, rocprim::plus<uint32_t>(), s) != hipSuccess) return -1;
     if (a.slots == 2)
         hipLaunchKernelGGL((sw_plan_records<2>), dim3(blocks_for(a.n_fill, a.n_cu)), dim3(256), 0, s, a.keys_b, a.vals_b, scan, a.len, a.buckets, a.n_fill, n,
                            a.longest, a.img0, a.groups, a.waves_tmp, a.wave_keys_a, a.wave_ids_a, a.padded);
@@ -155,7 +158,7 @@ int agx_sw_plan_launch(const SwPlanArgs &a, hipStream_t s)
         hipLaunchKernelGGL((sw_plan_records<1>), dim3(blocks_for(a.n_fill, a.n_cu)), dim3(256), 0, s, a.keys_b, a.vals_b, scan, a.len, a.buckets, a.n_fill, n,
                            a.longest, a.img0, a.groups, a.waves_tmp, a.wave_keys_a, a.wave_ids_a, a.padded);
     tb = a.temp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(a.temp, tb, a.wave_keys_a, a.wave_keys_b, a.wave_ids_a, a.wave_ids_b, (int)a.n_waves, 0, 24, s) != hipSuccess)
+    if (rocprim::radix_sort_pairs(a.temp, tb, a.wave_keys_a, a.wave_keys_b, a.wave_ids_a, a.wave_ids_b, (size_t)a.n_waves, 0u, 24u, s) != hipSuccess)
         return -1;
     hipLaunchKernelGGL(sw_plan_gather, dim3(blocks_for(a.n_waves, a.n_cu)), dim3(256), 0, s, a.waves_tmp, a.wave_ids_b, a.n_waves, a.waves);
     return hipGetLastError() == hipSuccess ? 0 : -1;
