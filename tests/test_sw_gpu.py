@@ -455,3 +455,27 @@ def test_device_planned_batch_with_waves_of_every_kind(ctx, oracle):
     assert np.array_equal(s_dev[sub], oracle_api.sw_batch_mt(oracle, b.subset(sub)))
     s_host, i_host = _planned(ctx, b, agx.SW_PLANNER_HOST)
     assert np.array_equal(s_host, s_dev) and i_host.padded_cells == i_dev.padded_cells and i_host.n_waves == i_dev.n_waves
+
+
+def test_int32_kernel_with_the_coded_match_across_scorings(ctx, oracle):
+    """AGX_SW_KERNEL_INT32 runs the packed plan's DNA-coded image in 32-bit state (agx_sw_i32d_kernel.hip) wherever the
+    coded match exists, else agx_sw_kernel.inc's cell: several scorings (one with match - mismatch >= 128: no coded
+    match), waves with a fifth symbol (general 32-bit cell), empty sides, odd pair counts, sequences without newline."""
+    rng = np.random.default_rng(5)
+    b = synth.sw_pairs(6001, 1, 330, seed=61, related_frac=0.5)
+    for p in rng.choice(b.n_pairs, size=400, replace=False):
+        k = 2 * int(p) + int(rng.integers(0, 2))
+        if b.len[k] > 1:
+            b.bases[int(b.off[k]) + int(rng.integers(0, int(b.len[k]) - 1))] = ord("N")
+    b.len[2 * 33] = 0
+    nonl = synth.sw_pairs(500, 20, 200, seed=62, related_frac=0.5, newline=False)
+    ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_INT32)
+    try:
+        for batch in (b, nonl):
+            for scoring in ((1, -1, -3, -1), (2, -3, -5, -2), (5, -4, -10, -1), (1, 0, 0, -1), (12, -116, -30, -7), (3, -1, 0, 0)):
+                dev = ctx.sw_batch(batch, scoring=scoring)
+                dev.launch()
+                assert np.array_equal(dev.scores(), oracle.sw_batch_scored(batch, scoring)), scoring
+                dev.close()
+    finally:
+        ctx.set_option(agx.OPT_SW_KERNEL, agx.SW_KERNEL_AUTO)
