@@ -204,9 +204,24 @@ Tiling choose_tiling_uniform(const double *costs, int slots, int lx, int ly, int
     return best;
 }
 
-// agx_sw_score sends a large batch through in pieces (upload of piece k + 1 beside the fill of piece k)
-constexpr uint64_t kPieceBytes = (uint64_t)64 << 20;
-constexpr int64_t kPieceMinPairs = 65536;
+// agx_sw_score sends a large batch through in pieces (upload of piece k + 1 beside the fill of piece k); tuning build:
+// AGX_SW_PIECE_MB, AGX_SW_PIECE_MIN_PAIRS
+inline uint64_t piece_bytes()
+{
+    static const uint64_t v = [] {
+        const char *e = agx_tune("AGX_SW_PIECE_MB");
+        return (uint64_t)(e && atoi(e) > 0 ? atoi(e) : 32) << 20;
+    }();
+    return v;
+}
+inline int64_t piece_min_pairs()
+{
+    static const int64_t v = [] {
+        const char *e = agx_tune("AGX_SW_PIECE_MIN_PAIRS");
+        return (int64_t)(e && atoi(e) > 0 ? atoi(e) : 32768);
+    }();
+    return v;
+}
 constexpr size_t kRawPad = 64;       // bytes in front of and behind the uploaded sequences (16-byte aligned pieces, agx_sw_pack_kernel.hip)
 constexpr uint8_t kClsEmpty = 255;   // an empty side: nothing to fill
 constexpr uint8_t kClsUntiled = 254; // pass A done, no tiling yet
@@ -1602,13 +1617,13 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
                  int32_t *scores)
 {
     AGX_GUARD_BEGIN
-    // A large batch goes through in contiguous pieces of about 64 MB of sequence: piece k + 1 is uploaded, planned and
+    // A batch of 64 MB and more goes through in up to eight contiguous pieces of at least 32 MB of sequence: piece k + 1 is uploaded, planned and
     // packed (copy and planning streams) while piece k is being filled (launch stream), so the call lasts about as
     // long as the upload plus the last piece's fill instead of upload + fill (1 048 576 mixed pairs, 573 MB, from
     // page-locked memory: 20.7 -> see DESIGN.md section 7).  Scores are fetched at the end, piece by piece, into the
     // caller's array.
     int pieces = 1;
-    if (ctx && n_pairs >= 2 * kPieceMinPairs && len) {
+    if (ctx && n_pairs >= 2 * piece_min_pairs() && len) {
         std::vector<uint64_t> part((size_t)agx_host_threads(), 0);
         agx_parallel_for(n_pairs, 65536, [&](int64_t lo, int64_t hi, int t) {
             uint64_t s = 0;
@@ -1617,7 +1632,9 @@ int agx_sw_score(agx_ctx *ctx, const uint8_t *bases, const uint64_t *off, const 
         });
         uint64_t bytes = 0;
         for (uint64_t v : part) bytes += v;
-        pieces = (int)std::min<uint64_t>({(uint64_t)16, bytes / kPieceBytes, (uint64_t)(n_pairs / kPieceMinPairs)});
+        // at most eight pieces (more cost a pageable source's staging more than they hide), none below 32 MB / 32 768 pairs
+        // (tools/piece_size_sweep.sh: config 4's 72 MB shard 2.96 -> 2.31 ms in two pieces, 2.73 in four)
+        pieces = (int)std::min<uint64_t>({(uint64_t)8, bytes / piece_bytes(), (uint64_t)(n_pairs / piece_min_pairs())});
         if (pieces < 2) pieces = 1;
     }
     if (pieces == 1) {
