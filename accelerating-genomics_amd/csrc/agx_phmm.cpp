@@ -670,6 +670,9 @@ struct agx_phmm_batch {
     bool file_order = false;
     double *bound = nullptr;
     PinBuf bound_flag;
+    // the fast cell's table rows of every read, made once at creation (phmm_pk_rows); rows_base_dw: image word of the first read
+    DevBuf pk_rows;
+    uint32_t rows_base_dw = 0;
 };
 
 namespace {
@@ -851,6 +854,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         img_dw += probs ? R * 8 + trk : 5 * trk;
         if (img_dw > 0xfffffff0ull) break;
     }
+    const size_t reads_end_dw = img_dw; // the reads' tracks lie in [zero_dw, reads_end_dw), 5 x ceil(R / 4) words each
     for (uint32_t h = 0; h < n_haps && img_dw <= 0xfffffff0ull; ++h) {
         hap_dw[h] = (uint32_t)img_dw;
         img_dw += hap_block_dw((size_t)(d->hap_off[h + 1] - d->hap_off[h]));
@@ -1101,6 +1105,36 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     if (e == hipSuccess && !pstripe.waves.empty()) e = hipMemsetAsync(b->stripe_scratch.p, 0, b->stripe_scratch.bytes, cs);
     if (e == hipSuccess) e = hipMemsetAsync(b->sums.p, 0, b->sums.bytes, cs); // degenerate pairs keep sum 0
     if (e == hipSuccess) e = hipMemsetAsync(b->counter.p, 0, b->counter.bytes, cs);
+    // The fast cell's table rows -- two float4 of derived constants per read position, several double divisions each --
+    // are the same in every wave that uses a read and in every launch of the batch: made here, once (phmm_pk_rows), the
+    // waves copy them into LDS instead of deriving them (3 % of config 3's launch).
+    PinBuf h_reads;
+    struct ReadsGuard {
+        PinBuf &p;
+        ~ReadsGuard() { p.release(); }
+    } reads_guard{h_reads};
+    if (e == hipSuccess && b->fast && !probs && n_reads && !agx_tune("AGX_PHMM_NO_ROWS")) {
+        const size_t n_rows = (reads_end_dw - zero_dw) / 5 * 4;
+        rc = b->pk_rows.alloc(ctx, std::max<size_t>(n_rows, 1) * 32);
+        DevBuf d_reads;
+        if (!rc) rc = h_reads.alloc(ctx, (size_t)n_reads * sizeof(PhTab));
+        if (!rc) rc = d_reads.alloc(ctx, (size_t)n_reads * sizeof(PhTab));
+        if (rc) {
+            d_reads.release();
+            return rc;
+        }
+        PhTab *hr = (PhTab *)h_reads.p;
+        for (uint32_t r = 0; r < n_reads; ++r) hr[r] = PhTab{read_dw[r], (uint32_t)(d->read_off[r + 1] - d->read_off[r])};
+        b->rows_base_dw = (uint32_t)zero_dw;
+        e = hipMemcpyAsync(d_reads.p, h_reads.p, (size_t)n_reads * sizeof(PhTab), hipMemcpyHostToDevice, cs);
+        const void *lut_f = (const char *)b->lut.p + 256 * sizeof(double);
+        const void *mis_f = (const char *)b->lut.p + 256 * (2 * sizeof(double) + sizeof(float));
+        if (e == hipSuccess && agx_phmm_pk_rows_launch((const uint32_t *)b->img.p, (const PhTab *)d_reads.p, n_reads, lut_f, gatk_prior ? mis_f : nullptr,
+                                                       b->pk_rows.p, b->rows_base_dw, cs))
+            e = hipErrorLaunchFailure;
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        d_reads.release();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(cs);
     if (e != hipSuccess) {
         agx_set_error("agx_phmm_batch_create: upload -> %s", hipGetErrorString(e));
@@ -1132,6 +1166,7 @@ void agx_phmm_batch_destroy(agx_phmm_batch *b)
     b->sums.release();
     b->out_stage.release();
     b->bound_flag.release();
+    b->pk_rows.release();
     b->lut.release();
     b->counter.release();
     agx_ctx_release(b->ctx); // the batch's own reference: a context outlives its batches
@@ -1209,7 +1244,8 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                                                        mis_for_f, (double *)b->sums.p,
                                                        PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1,
                                                                    (double)(FLT_MAX / 16), (float)((b->gatk_prior ? kGuardGatk : kGuardRef) * 3.3219280948873623),
-                                                                   b->bound, b->bound ? (unsigned *)b->bound_flag.p : nullptr, log10((double)(FLT_MAX / 16))},
+                                                                   b->bound, b->bound ? (unsigned *)b->bound_flag.p : nullptr, log10((double)(FLT_MAX / 16)),
+                                                                   b->pk_rows.p, b->rows_base_dw},
                                                        cl.lds, st);
                 if (r) {
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));

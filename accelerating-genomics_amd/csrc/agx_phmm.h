@@ -111,7 +111,14 @@ struct PhUnderflow {
     double *logs_host;
     unsigned *flag_host;
     double log_c32;
+    // the fast cell's table rows made once per batch (phmm_pk_rows: two float4 per read position, the read whose tracks
+    // start at image word d at row (d - rows_base_dw) / 5 * 4); NULL: every wave derives its rows itself
+    const void *pk_rows;
+    uint32_t rows_base_dw;
 };
+// makes those rows for every read of `reads` (one PhTab per read); lut / lut_mis as the packed fill takes them
+int agx_phmm_pk_rows_launch(const uint32_t *img, const PhTab *reads, uint32_t n_reads, const void *lut, const void *lut_mis, void *rows,
+                            uint32_t rows_base_dw, hipStream_t s);
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              const PhUnderflow &uf, size_t lds_bytes, hipStream_t s);

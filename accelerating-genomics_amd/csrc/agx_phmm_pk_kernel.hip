@@ -59,6 +59,53 @@ __device__ __forceinline__ f2 rshr1(f2 v)
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// One row of the fast cell's table for read position i (0 <= i < R): {pq D, 2 (pm - pq) D, (1-(Qi+Qd)) / D-, Qi gm+ / D- |
+// Qg gm+ / gm, -, Qg, T} (D = Qd gm+ of this row, D- of the previous one; see phmm_fill_pk_body).  rp: the read's five
+// byte tracks, trk bytes each.  Used by the fill (a wave deriving its own rows) and by phmm_pk_rows (once per batch).
+__device__ __forceinline__ void pk_fast_row(const unsigned char *__restrict__ rp, uint32_t trk, int R, int i, const float *__restrict__ lut,
+                                            const float *__restrict__ lut_mis, float4 &ra, float4 &rb)
+{
+    const uint32_t c = rp[i];
+    const float vr = lut[rp[trk + i]];
+    const float vm = lut_mis ? lut_mis[rp[trk + i]] : vr; // Qr/3 with AGX_PHMM_GATK_PRIOR, else Qr itself
+    const float vi = lut[rp[2 * trk + i]], vd = lut[rp[3 * trk + i]], vg = lut[rp[4 * trk + i]];
+    const float pm = 1 - vr;                       // p(): match or N
+    const float pq = c == (uint32_t)'N' ? pm : vm; //      mismatch
+    auto gm_of = [&](int k) -> float { // 1 - Qg of read row k, extended to both sides
+        if (k >= R) return 1.f;
+        return 1 - lut[rp[4 * trk + (k < 0 ? 0 : k)]];
+    };
+    const double g = gm_of(i), gp = gm_of(i + 1);
+    auto d_of = [&](int k) -> double { // D of read row k; 1 outside the read and in its last row
+        if (k < 0 || k >= R - 1) return 1.0;
+        return (double)lut[rp[3 * trk + k]] * (double)gm_of(k + 1);
+    };
+    const double dcur = d_of(i), dprev = d_of(i - 1);
+    const uint32_t tbl = c == (uint32_t)'N' ? 0x3f3f3f3fu : 0x3fu << (8u * ((c >> 1) & 3u));
+    ra = float4{(float)((double)pq * dcur), (float)(2 * ((double)pm - (double)pq) * dcur), (float)((1 - ((double)vi + (double)vd)) / dprev),
+                (float)((double)vi * gp / dprev)};
+    rb = float4{(float)((double)vg * gp / g), 0.f, vg, __uint_as_float(tbl)};
+}
+
+// every read's rows, once per batch: one workgroup of 64 threads per read
+__global__ void __launch_bounds__(64) phmm_pk_rows(const uint32_t *__restrict__ img, const PhTab *__restrict__ reads, uint32_t n_reads,
+                                                   const float *__restrict__ lut, const float *__restrict__ lut_mis, float4 *__restrict__ rows,
+                                                   uint32_t rows_base_dw)
+{
+    const uint32_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const PhTab tb = reads[r];
+    const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
+    const uint32_t trk = ((tb.R + 3u) >> 2) * 4u;
+    float4 *dst = rows + 2 * (size_t)((tb.read_dw - rows_base_dw) / 5u * 4u);
+    for (uint32_t i = threadIdx.x; i < tb.R; i += 64) {
+        float4 a, b;
+        pk_fast_row(rp, trk, (int)tb.R, (int)i, lut, lut_mis, a, b);
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
+    }
+}
+
 // ROW16: every wave of the launch has groups of exactly 16 lanes (uniform batches such as H = 300 in 16 x 19):
 // the groups coincide with the DPP rows, and the row shift's zero fill is the column-0 boundary.
 template <int C, bool ROW16, bool FAST>
@@ -105,6 +152,7 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
         float4 *tr = reinterpret_cast<float4 *>(lds + k * tab_bytes);
         const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
         const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
+        const float4 *pre = (FAST && uf.pk_rows) ? reinterpret_cast<const float4 *>(uf.pk_rows) + 2 * (size_t)((tb.read_dw - uf.rows_base_dw) / 5u * 4u) : nullptr;
         for (uint32_t r = lane; r < rows; r += 64) {
             const int i = (int)r - (G - 1);
             float vr = 0, vi = 0, vd = 0, vg = 1, vm = 0; // neutral row
@@ -120,28 +168,18 @@ __device__ __forceinline__ void phmm_fill_pk_body(const uint32_t *__restrict__ i
             const float pm = 1 - vr;                          // p(): match or N
             const float pq = c == (uint32_t)'N' ? pm : vm;    //      mismatch
             if constexpr (FAST) {
-                auto gm_of = [&](int k) -> float { // 1 - Qg of read row k, extended to both sides
-                    if (k >= (int)tb.R) return 1.f;
-                    return 1 - lut[rp[4 * trk + (k < 0 ? 0 : k)]];
-                };
-                const double g = gm_of(i), gp = gm_of(i + 1);
-                // M is carried times this row's D = Qd gm+ (what the Y chain multiplies it with), except in the last row,
-                // whose Y nobody reads: D = 1 there, so the final sum sees the true M.  The factor folds into the priors
-                // (M_stored = (prior D) * u) and out of the two other uses of M through the previous row's D.
-                auto d_of = [&](int k) -> double { // D of read row k; 1 outside the read and in its last row
-                    if (k < 0 || k >= (int)tb.R - 1) return 1.0;
-                    return (double)lut[rp[3 * trk + k]] * (double)gm_of(k + 1);
-                };
-                const double dcur = d_of(i), dprev = d_of(i - 1);
-                // (a neutral row's priors are BOTH zero here: the plain cell's neutral rows keep M = 0 through gm = 0,
-                // which this cell no longer multiplies with -- a haplotype N would match the row and pick 1 - Qr = 1)
-                const bool real = i >= 0 && i < (int)tb.R;
-                // (the prior starts from the MISMATCH value and a match adds pm - pq: the other way round -- matches exact,
-                // mismatches pm - (pm - pq) -- cancels: errors of 1e-4 in log10 L, measured)
-                const uint32_t tbl = !real ? 0u : c == (uint32_t)'N' ? 0x3f3f3f3fu : 0x3fu << (8u * ((c >> 1) & 3u));
-                tr[2 * r] = float4{real ? (float)((double)pq * dcur) : 0.f, real ? (float)(2 * ((double)pm - (double)pq) * dcur) : 0.f,
-                                   (float)((1 - ((double)vi + (double)vd)) / dprev), (float)((double)vi * gp / dprev)};
-                tr[2 * r + 1] = float4{(float)((double)vg * gp / g), 0.f, vg, __uint_as_float(tbl)};
+                // (a neutral row: both priors zero, every factor one -- the scaled state passes through it unchanged; the plain
+                // cell's neutral rows keep M = 0 through gm = 0, which this cell no longer multiplies with)
+                float4 fa = float4{0.f, 0.f, 1.f, 0.f}, fb = float4{1.f, 0.f, 1.f, 0.f};
+                if (i >= 0 && i < (int)tb.R) {
+                    if (pre) { // made once per batch (phmm_pk_rows)
+                        fa = pre[2 * i];
+                        fb = pre[2 * i + 1];
+                    } else
+                        pk_fast_row(rp, trk, (int)tb.R, i, lut, lut_mis, fa, fb);
+                }
+                tr[2 * r] = fa;
+                tr[2 * r + 1] = fb;
             } else {
                 tr[2 * r] = float4{pm, pq, 1 - (vi + vd), 1 - vg}; // mm() (:115-117)
                 tr[2 * r + 1] = float4{vi, vd, vg, __uint_as_float(c)};
@@ -443,6 +481,15 @@ int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, c
 #undef AGX_PH_PK_CASE
     default: return -2;
     }
+}
+
+int agx_phmm_pk_rows_launch(const uint32_t *img, const PhTab *reads, uint32_t n_reads, const void *lut, const void *lut_mis, void *rows,
+                            uint32_t rows_base_dw, hipStream_t s)
+{
+    if (n_reads == 0) return 0;
+    hipLaunchKernelGGL(phmm_pk_rows, dim3(n_reads), dim3(64), 0, s, img, reads, n_reads, (const float *)lut, (const float *)lut_mis, (float4 *)rows,
+                       rows_base_dw);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // Loads this file's code object now: the first launch of a kernel otherwise pays for it (1-2 ms in a fresh process --
