@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # only (libagx_tuning.so, -DAGX_TUNING): a process that sets one of them gets that library.
 TUNING_KNOBS = ("AGX_SW_KERNEL", "AGX_SW_TAIL_BETA", "AGX_SW_MAX_C", "AGX_SW_FORCE_C", "AGX_SW_MAX_CLASSES", "AGX_SW_WAVES_PER_CLASS",
                 "AGX_SW_SORT_WAVES", "AGX_SW_ONE_LAUNCH", "AGX_SW_DNA", "AGX_SW_RISE", "AGX_PHMM_PLAIN_CELL", "AGX_TRACE_CREATE", "AGX_HOST_THREADS", "AGX_FANOUT", "AGX_PHMM_TAB_BUDGET", "AGX_PHMM_MAX_C",
-                "AGX_PHMM_FORCE_C", "AGX_PHMM_TAIL_BETA", "AGX_PHMM_MAX_CLASSES", "AGX_PHMM_NO_LUT", "AGX_TRACE_POOL", "AGX_NO_STREAM_PRIO", "AGX_SW_I32_CLASSIC", "AGX_SW_PIECE_MB", "AGX_SW_PIECE_MIN_PAIRS", "AGX_PHMM_NO_ROWS")
+                "AGX_PHMM_FORCE_C", "AGX_PHMM_TAIL_BETA", "AGX_PHMM_MAX_CLASSES", "AGX_PHMM_NO_LUT", "AGX_TRACE_POOL", "AGX_NO_STREAM_PRIO", "AGX_SW_I32_CLASSIC", "AGX_SW_PIECE_MB", "AGX_SW_PIECE_MIN_PAIRS", "AGX_PHMM_NO_ROWS", "AGX_PHMM_NO_TRAINS")
 _DEFAULT_LIB = "libagx_tuning.so" if any(k in os.environ for k in TUNING_KNOBS) else "libagx.so"
 LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, _DEFAULT_LIB))  # override: kernel experiments only
 
@@ -21,6 +21,8 @@ OK, E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_SYMBOL, E_LIMIT, E_IO = 0, -1, -2, -3, 
 OPT_SW_KERNEL = 1
 OPT_SW_PLANNER = 2
 SW_PLANNER_AUTO, SW_PLANNER_HOST, SW_PLANNER_DEVICE = 0, 1, 2
+OPT_PHMM_TRAINS = 3
+PHMM_TRAINS_AUTO, PHMM_TRAINS_OFF, PHMM_TRAINS_ON = 0, 1, 2
 SW_KERNEL_AUTO, SW_KERNEL_INT32, SW_KERNEL_PACKED_SIGNED, SW_KERNEL_PACKED_BIASED = 0, 1, 2, 3
 PHMM_F64, PHMM_F64_FMA, PHMM_F32, PHMM_F32_FMA = 0, 1, 2, 3
 PHMM_GATK_PRIOR = 0x100  # OR-able into the precision

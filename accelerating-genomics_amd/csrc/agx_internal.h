@@ -93,6 +93,7 @@ struct agx_ctx {
     // options (agx_ctx_set_option)
     int opt_sw_kernel = 0;
     int opt_sw_planner = 0;
+    int opt_phmm_trains = 0;
 };
 
 int agx_ctx_prepare_fanout(agx_ctx *c); // side streams + events for batches of several launches

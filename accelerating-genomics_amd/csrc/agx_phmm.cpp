@@ -194,6 +194,10 @@ struct PlanOut {
     std::vector<PhWave> waves;
     std::vector<ClassLaunch> launches;
     int64_t padded = 0;
+    // where the padded cells go (AGX_TRACE_CREATE): [0] useful R x H, [1] columns beyond H (vacant halves included), [2] the G - 1
+    // steps of skew, [3] steps beyond a group's own R + G - 1 (the wave steps its longest read), [4] lanes without a group
+    int64_t waste[5] = {0, 0, 0, 0, 0};
+    bool trains = false; // packed plan: groups may carry a second read, every table has two PhTab entries (agx_phmm.h)
     bool file_order = false; // one (R, H) shape: the records are in output order (agx_phmm_batch_bind_results)
 };
 
@@ -228,7 +232,8 @@ std::vector<size_t> cut_at_runs(size_t n, int parts, F is_cut)
 // kind = row of kPhClassCost (0 f64, 1 f64 FMA, 2 f32, 3 packed f32 FMA); slots = pairs per group; lut_rows: the read
 // tables have the rows of agx_phmm_lut_kernel.hip; `gen` (a copy of seed.gen0, or seed.gen0 itself when nobody needs
 // it afterwards) is consumed.
-int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, bool rows_f64, bool lut_rows, bool trace, PlanOut &po)
+// trains: 0 = read trains where they pay (packed plans of enough waves), 1 = never, 2 = wherever two reads can share a group
+int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, bool rows_f64, bool lut_rows, bool trace, int trains, PlanOut &po)
 {
     const double tm0 = now_ms();
     double tm1 = tm0, tm2 = tm0, tm3 = tm0, tm4 = tm0;
@@ -482,7 +487,31 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     // Waves and records.  The greedy filling below runs on pieces of `plan` that start where the read, the class or
     // the group width changes (a wave never spans such a piece's end; a packed group's partner is the next haplotype of
     // the SAME read, so no group does either); the pieces' records are then laid end to end.
+    // Read trains (packed float fill, fast cell): two consecutive reads of the sorted order whose runs in this bucket hold
+    // the same haplotypes -- reads of one region -- share their lane groups: the second enters as the first leaves, the skew
+    // is paid once (K (R + 1) + G - 1 steps for K = 2 reads instead of K (R + G - 1)).  Measured envelope, tools/train_emulation.py:
+    // +5.4 % on config 3, +5.8 % at four times its size; trains of four +4 %, of eight a loss (their tables outgrow the LDS
+    // share of a wave).  Only where the paired waves still fill the chip: from two waves per SIMD after pairing.
+    bool use_trains = slots == 2 && trains != 1 && (trains == 2 || waves_est >= 16.0 * n_cu);
     auto fill_waves = [&](size_t i, const size_t end, PlanOut &o) {
+        size_t run_end = i, run_delta = 0; // the read run i is in ends at run_end; its partner run starts run_delta entries on (0: none)
+        auto find_partner = [&](size_t a) {
+            const uint32_t rd = plan[a].read;
+            const int cls = plan[a].cls, G = plan[a].G;
+            size_t a_end = a;
+            while (a_end < end && plan[a_end].read == rd && plan[a_end].cls == cls && plan[a_end].G == G) ++a_end;
+            run_end = a_end;
+            run_delta = 0;
+            if (a_end >= end || plan[a_end].cls != cls || plan[a_end].G != G) return;
+            const uint32_t rd2 = plan[a_end].read;
+            size_t b_end = a_end;
+            while (b_end < end && plan[b_end].read == rd2 && plan[b_end].cls == cls && plan[b_end].G == G) ++b_end;
+            if (b_end - a_end != a_end - a) return;
+            for (size_t k = 0; k < a_end - a; ++k)
+                if (plan[a + k].hap != plan[a_end + k].hap) return;
+            if (ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return;
+            run_delta = a_end - a;
+        };
         while (i < end) {
             const int cls = plan[i].cls;
             ClassLaunch cl;
@@ -500,7 +529,10 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                 size_t lut_bytes = 0; // lut_rows: every table is as long as its own read (+ a neutral row at either end)
                 while (i < end && plan[i].cls == cls && plan[i].G == G && cnt < per_wave) {
                     const Plan &p = plan[i];
-                    const uint32_t nsteps = std::max(steps, p.R + (uint32_t)G - 1u);
+                    if (use_trains && i >= run_end) find_partner(i);
+                    const size_t tr = use_trains ? run_delta : 0; // this entry's second read sits tr entries on
+                    const uint32_t R2 = tr ? plan[i + tr].R : 0u;
+                    const uint32_t nsteps = std::max(steps, p.R + (tr ? R2 + 1u : 0u) + (uint32_t)G - 1u);
                     const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
                     if (lut_rows) {
                         if (cnt > 0 && p.read != last_read && lut_bytes + ph_lut_tab_bytes(p.R + 2u) > tab_budget()) break;
@@ -509,6 +541,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                     if (p.read != last_read) {
                         // (lut_rows: the table's offset / 16 rides in the upper half of R, agx_phmm_lut_kernel.hip)
                         o.tabs.push_back(PhTab{read_dw[p.read], lut_rows ? p.R | (uint32_t)(lut_bytes / 16) << 16 : p.R});
+                        if (use_trains) o.tabs.push_back(tr ? PhTab{read_dw[plan[i + tr].read], R2} : PhTab{0u, 0u});
                         if (lut_rows) lut_bytes += ph_lut_tab_bytes(p.R + 2u);
                         last_read = p.read;
                     }
@@ -526,12 +559,16 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                         g.H[1] = 0;
                         g.out[1] = vacant_out;
                         g.init32[1] = 0;
+                        g.R2 = R2;
+                        g.out2[0] = tr ? plan[i + tr].out : vacant_out;
+                        g.out2[1] = vacant_out;
                         if (i + 1 < end && plan[i + 1].cls == cls && plan[i + 1].G == G && plan[i + 1].read == p.read) {
                             const Plan &q = plan[i + 1];
                             g.hap_dw[1] = hap_dw[q.hap];
                             g.H[1] = q.H;
                             g.out[1] = q.out;
                             g.init32[1] = FLT_MAX / 16 / (float)q.H;
+                            if (tr) g.out2[1] = plan[i + 1 + tr].out;
                             ++i;
                         }
                         o.groups2.push_back(g);
@@ -547,10 +584,35 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                     }
                     ++cnt;
                     ++i;
+                    if (use_trains && run_delta && i == run_end) { // the partner run rode along: step over it
+                        i += run_delta;
+                        run_end = i;
+                        run_delta = 0;
+                    }
                 }
                 w.n_groups = (uint16_t)cnt;
                 w.n_tabs = (uint16_t)ntabs;
                 w.steps = steps;
+                if (trace) {
+                    const int64_t cols = (int64_t)G * cl.C;
+                    for (int k = 0; k < cnt; ++k) {
+                        uint32_t R = 0, H[2] = {0, 0}, extra = 0; // extra: a train's reset row
+                        if (slots == 2) {
+                            const PhGroup2 &g = o.groups2[w.first_group + (size_t)k];
+                            R = (g.R_tab & 0xffffu) + g.R2, H[0] = g.H[0], H[1] = g.H[1], extra = g.R2 ? 1u : 0u;
+                        } else {
+                            const PhGroup &g = o.groups1[w.first_group + (size_t)k];
+                            R = g.R_tab & 0xffffu, H[0] = g.H;
+                        }
+                        for (int h = 0; h < slots; ++h) {
+                            o.waste[0] += (int64_t)R * H[h];
+                            o.waste[1] += (int64_t)R * (cols - H[h]);
+                            o.waste[2] += (int64_t)(G - 1 + (int)extra) * cols;
+                            o.waste[3] += (int64_t)(steps - (R + extra + (uint32_t)G - 1u)) * cols;
+                        }
+                    }
+                    o.waste[4] += (int64_t)steps * (64 - (int64_t)cnt * G) * cl.C * slots;
+                }
                 if (G != 16) cl.all_g16 = false;
                 cl.lds = std::max(cl.lds, lut_rows ? lut_bytes : tab_bytes(rows_f64, steps + G - 1) * ntabs);
                 cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
@@ -565,6 +627,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
         return plan[i].read != plan[i - 1].read || plan[i].cls != plan[i - 1].cls || plan[i].G != plan[i - 1].G;
     });
     const int pieces = (int)cut.size() - 1;
+    auto build = [&](PlanOut &po) {
     if (pieces <= 1)
         fill_waves(0, plan.size(), po);
     else {
@@ -589,6 +652,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             g0[(size_t)t] = ga, t0[(size_t)t] = ta, w0[(size_t)t] = wa;
             ga += o.groups1.size() + o.groups2.size(), ta += o.tabs.size(), wa += o.waves.size();
             po.padded += o.padded;
+            for (int k = 0; k < 5; ++k) po.waste[k] += o.waste[k];
             for (ClassLaunch cl : o.launches) { // a class that runs on into the next piece is one launch
                 cl.first_wave += (uint32_t)w0[(size_t)t];
                 if (!po.launches.empty() && po.launches.back().C == cl.C) {
@@ -616,6 +680,27 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             }
         });
     }
+    };
+    if (use_trains) {
+        // Trains double a table: where a wave's groups come from several reads (mixed regions: a read's haplotype pairs do
+        // not fill a wave) fewer tables fit the wave's LDS share and lanes stay empty -- on the reference's corpus shape
+        // useful cells 0.85 -> 0.77.  Both plans are made (the wave filling is a tenth of the planner) and the one with
+        // fewer padded cells stays; forced trains (AGX_PHMM_TRAINS_ON) skip the comparison.
+        PlanOut with;
+        build(with);
+        with.trains = true;
+        bool keep = trains == 2;
+        if (!keep) {
+            use_trains = false;
+            build(po);
+            keep = (double)with.padded < 0.985 * (double)po.padded;
+        }
+        if (keep) {
+            with.file_order = po.file_order;
+            po = std::move(with);
+        }
+    } else
+        build(po);
     for (const ClassLaunch &cl : po.launches) {
         // dispatch order = longest waves first (a wave lasts steps x C): the buckets were filled widest
         // group first, which leaves narrow groups with long reads for the end of the launch
@@ -630,6 +715,14 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     if (trace)
         fprintf(stderr, "[phmm make_plan kind %d] pairing+shapes %.2f, tiling %.2f, assign %.2f, sort %.2f, waves+records %.2f ms (%d pieces)\n",
                 kind, tm1 - tm0, tm2 - tm1, tm3 - tm2, tm4 - tm3, now_ms() - tm4, pieces);
+    if (trace && po.padded > 0) {
+        const double t = (double)po.padded;
+        fprintf(stderr, "[phmm make_plan kind %d] %zu waves, padded cells %.4g: useful %.3f, columns beyond H %.3f, skew %.3f, steps beyond the group's read %.3f, "
+                        "lanes without a group %.3f; read trains %d; classes",
+                kind, po.waves.size(), t, po.waste[0] / t, po.waste[1] / t, po.waste[2] / t, po.waste[3] / t, po.waste[4] / t, (int)po.trains);
+        for (const ClassLaunch &cl : po.launches) fprintf(stderr, " %dx%u", cl.C, cl.n_waves);
+        fprintf(stderr, "\n");
+    }
     return AGX_OK;
 }
 
@@ -651,6 +744,7 @@ struct agx_phmm_batch {
     bool packed = false;          // main plan uses PhGroup2 records (AGX_PHMM_F32_FMA)
     bool rescue_pending = false;  // packed batches: the rescue plan has not run for the last launch (it runs from
                                   // agx_phmm_batch_results, and only when the fill counted a pair below the float range)
+    bool trains = false;          // ... with read trains (PlanOut::trains)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
     bool lut_prior = false;       // double modes on plain DNA: priors looked up in the read tables (agx_phmm_lut_kernel.hip)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches), made on first use from:
@@ -664,6 +758,7 @@ struct agx_phmm_batch {
     } main, rescue, stripe; // stripe: pairs whose haplotype no class spans, one per wavefront
     DevBuf stripe_scratch;    // 6 * stripe_rows doubles per workgroup of the striped launch
     uint32_t stripe_rows = 0, stripe_grid = 0;
+    bool stripe_mis_div = false; // the striped launch derives the GATK mismatch prior itself (see create)
     agx_phmm_info info{};
     // agx_phmm_batch_bind_results: a page-locked array of the caller's that a packed float fill in output order writes its
     // log10 likelihoods into itself; bound_flag (in out_stage) says whether a pair went to the rescue plan instead
@@ -888,6 +983,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // gap-continuation quality of Phred 0 or below, a read base outside ACGTN or a haplotype base outside ACGT anywhere
     // in the batch keeps the plain cell
     std::atomic<bool> not_fast{false}, not_dna{false}; // not_dna: a read base outside ACGTN or a haplotype base outside ACGT
+    std::atomic<bool> wild{false};                     // a quality byte below '!' (as a signed char): no read trains
     static const auto dna_table = [] {
         std::array<uint8_t, 256> t{};
         for (const char *p = "ACGT"; *p; ++p) t[(uint8_t)*p] = 3; // bit 0: allowed in a read, bit 1: in a haplotype
@@ -896,13 +992,15 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     }();
     if (have_tracks) {
         agx_parallel_for((int64_t)n_reads, 2048, [&](int64_t ra, int64_t rz, int) {
-            bool zero = false, other = false;
+            bool zero = false, other = false, low = false;
             for (int64_t r = ra; r < rz && !probs && precision != AGX_PHMM_F32; ++r)
                 for (uint64_t k = d->read_off[r]; k < d->read_off[r + 1]; ++k) {
                     zero |= packed && (int8_t)d->q_gcp[k] <= (int8_t)'!'; // signed as the reference's char: 0x80.. are "probabilities" above 1
                     other |= !(dna_table[d->read_bases[k]] & 1);
+                    low |= packed && ((int8_t)d->q_base[k] < (int8_t)'!' || (int8_t)d->q_ins[k] < (int8_t)'!' || (int8_t)d->q_del[k] < (int8_t)'!');
                 }
             if (zero || other) not_fast.store(true, std::memory_order_relaxed);
+            if (low) wild.store(true, std::memory_order_relaxed);
             if (other) not_dna.store(true, std::memory_order_relaxed);
             for (int64_t r = ra; r < rz; ++r) {
                 const uint64_t o = d->read_off[r];
@@ -953,8 +1051,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
                            !agx_tune("AGX_PHMM_NO_LUT");
     const size_t n_work = gen0.size(); // pairs with work (every pair of the batch, unless a read or haplotype is empty)
     PlanOut pmain;
-    rc = packed ? make_plan(seed, gen0, 3, 2, false, false, trace, pmain)
-                : make_plan(seed, std::move(gen0), precision, 1, f64, lut_prior, trace, pmain);
+    // read trains: the fast cell only, and only on qualities that are probabilities (a byte below '!' is a "probability"
+    // above 1: a first read whose state ran to infinity there would hand NaN to the second through the reset row's 0 x inf)
+    const int trains_opt = ctx ? ctx->opt_phmm_trains : AGX_PHMM_TRAINS_AUTO;
+    const bool may_train = packed && !not_fast.load() && !wild.load() && !agx_tune("AGX_PHMM_PLAIN_CELL") && !agx_tune("AGX_PHMM_NO_TRAINS");
+    rc = packed ? make_plan(seed, gen0, 3, 2, false, false, trace, may_train ? (trains_opt == AGX_PHMM_TRAINS_ON ? 2 : trains_opt == AGX_PHMM_TRAINS_OFF ? 1 : 0) : 1, pmain)
+                : make_plan(seed, std::move(gen0), precision, 1, f64, lut_prior, trace, 1, pmain);
     if (rc) return rc;
     // striped plan: one pair per wavefront, every pair its own read table
     PlanOut pstripe;
@@ -983,6 +1085,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         const int64_t n_stripes = (p.H + 64 * stripe_cols() - 1) / (64 * stripe_cols());
         pstripe.padded += n_stripes * w.steps * 64 * stripe_cols();
     }
+    // The GATK prior's fifth table column (Qr / 3) does not fit beside the others for reads beyond 3 870 bases (41 bytes x
+    // (R + 126) rows > 160 KiB): the striped launch then keeps four columns and divides in its step head -- the same IEEE
+    // division the host's table was made with, so the results do not change.
+    bool stripe_mis_div = false;
+    if (gatk_prior && stripe_lds > 160 * 1024) {
+        stripe_mis_div = true;
+        stripe_lds = ph_tab_bytes(true, false, stripe_steps + 63u);
+    }
     if (stripe_lds > 160 * 1024) {
         agx_set_error("a read table of %zu bytes does not fit the 160 KiB LDS", stripe_lds);
         return AGX_E_LIMIT;
@@ -1008,10 +1118,12 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->packed = packed;
     b->file_order = packed && pmain.file_order && pstripe.waves.empty() && (int64_t)n_work == n_pairs;
     b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
+    b->trains = packed && pmain.trains;
     b->lut_prior = lut_prior;
     // the code objects this batch will launch from, loaded now rather than inside its first launch
     if (ctx) {
         if (packed) agx_phmm_pk_preload();
+        if (packed && pmain.trains) agx_phmm_pk_train_preload();
         agx_phmm_scalar_preload();
         if (lut_prior) agx_phmm_lut_preload();
         agx_copy_preload();
@@ -1038,6 +1150,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
         cl.lds = cl.lds_rescue = stripe_lds;
         b->stripe.launches.push_back(cl);
         b->info.n_launches += 1;
+        b->stripe_mis_div = stripe_mis_div;
         b->stripe_rows = (stripe_steps + 128u + 63u) & ~63u; // a 64-row block may start at the last step, 63 rows ahead
         b->stripe_grid = std::min<uint32_t>(cl.n_waves, (uint32_t)n_cu * 8u);
     }
@@ -1227,7 +1340,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
             // a float batch's long pairs are computed in double: stored negated like its rescued pairs
             const int r = agx_phmm_stripe_launch(mode, cl.C, (const uint32_t *)b->img.p, (const PhGroup *)b->stripe.groups.p,
                                                  (const PhTab *)b->stripe.tabs.p, (const PhWave *)b->stripe.waves.p, cl.n_waves,
-                                                 b->stripe_grid, lut_d, mis_for_d, (double *)b->sums.p,
+                                                 b->stripe_grid, lut_d, b->stripe_mis_div ? nullptr : mis_for_d, b->stripe_mis_div ? 1 : 0, (double *)b->sums.p,
                                                  (double *)b->stripe_scratch.p, b->stripe_rows, f32_family ? 1 : 0, cl.lds,
                                                  fan.stream(k++));
             if (r) {
@@ -1238,15 +1351,16 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
         for (const ClassLaunch &cl : b->main.launches) {
             hipStream_t st = fan.stream(k++);
             if (b->packed) {
-                const int r = agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->fast, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
-                                                       (const PhTab *)b->main.tabs.p,
-                                                       (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_f,
-                                                       mis_for_f, (double *)b->sums.p,
-                                                       PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1,
+                const PhUnderflow uf = PhUnderflow{(double)AGX_PHMM_F32_RESCUE, (uint32_t)b->n_pairs, (unsigned long long *)b->counter.p + 1,
                                                                    (double)(FLT_MAX / 16), (float)((b->gatk_prior ? kGuardGatk : kGuardRef) * 3.3219280948873623),
                                                                    b->bound, b->bound ? (unsigned *)b->bound_flag.p : nullptr, log10((double)(FLT_MAX / 16)),
-                                                                   b->pk_rows.p, b->rows_base_dw},
-                                                       cl.lds, st);
+                                                                   b->pk_rows.p, b->rows_base_dw};
+                const int r = b->trains ? agx_phmm_pk_train_launch_class(cl.C, cl.all_g16, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                                                                         (const PhTab *)b->main.tabs.p, (const PhWave *)b->main.waves.p + cl.first_wave,
+                                                                         cl.n_waves, lut_f, mis_for_f, (double *)b->sums.p, uf, cl.lds, st)
+                                        : agx_phmm_pk_launch_class(cl.C, cl.all_g16, b->fast, (const uint32_t *)b->img.p, (const PhGroup2 *)b->main.groups.p,
+                                                                   (const PhTab *)b->main.tabs.p, (const PhWave *)b->main.waves.p + cl.first_wave,
+                                                                   cl.n_waves, lut_f, mis_for_f, (double *)b->sums.p, uf, cl.lds, st);
                 if (r) {
                     agx_set_error("phmm_fill_pk<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
                     return AGX_E_HIP;
@@ -1292,7 +1406,7 @@ static int launch_rescue_plan(agx_phmm_batch *b)
         PlanOut pr;
         const bool trace = agx_tune("AGX_TRACE_CREATE") != nullptr;
         std::unique_ptr<PlanSeed> seed = std::move(b->rescue_seed);
-        int rc = make_plan(*seed, std::move(seed->gen0), AGX_PHMM_F64, 1, true, false, trace, pr);
+        int rc = make_plan(*seed, std::move(seed->gen0), AGX_PHMM_F64, 1, true, false, trace, 1, pr);
         if (rc) return rc;
         struct Piece {
             DevBuf *dst;

@@ -20,16 +20,20 @@ struct PhGroup {
 // Packed float kernel (AGX_PHMM_F32_FMA): one group of G lanes carries two haplotypes of the same
 // read ([0] in the x half, [1] in the y half of every float2).  A group without a second haplotype
 // points [1] at an empty haplotype (H = 0) and at the spare slot sums[n_pairs].
+// Read trains (round 3): the group fills a second read of R2 bases (0: none) behind the first without draining; its sums
+// go to out2[] (the spare slot when there is none).
 struct PhGroup2 {
     uint32_t hap_dw[2];
     uint32_t H[2];
     uint32_t out[2];
     float init32[2];
     uint32_t R_tab; // R | tab << 16
-    uint32_t reserved;
+    uint32_t R2;
+    uint32_t out2[2];
 };
 
 // One read table to build in LDS: the read's five tracks start at read_dw, each padded to 4 bytes.
+// (A launch with read trains has TWO entries per table: the first read, then the second or {0, 0}.)
 struct PhTab {
     uint32_t read_dw;
     uint32_t R;
@@ -122,6 +126,11 @@ int agx_phmm_pk_rows_launch(const uint32_t *img, const PhTab *reads, uint32_t n_
 int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
                              const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                              const PhUnderflow &uf, size_t lds_bytes, hipStream_t s);
+// the fast cell with read trains (two PhTab entries per table; agx_phmm_pk_train_kernel.hip)
+int agx_phmm_pk_train_launch_class(int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup2 *groups, const PhTab *tabs,
+                                   const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
+                                   const PhUnderflow &uf, size_t lds_bytes, hipStream_t s);
+void agx_phmm_pk_train_preload();
 // Haplotypes no class can span (more than 64 lanes x the widest class of the batch's arithmetic) run
 // one pair per wavefront in stripes of 64 x AGX_PH_STRIPE_COLS = 1536 columns, always in double (mode 0, 1
 // or 4).  grid workgroups walk the n_waves pairs; scratch holds 6 * scratch_rows doubles per workgroup.
@@ -129,8 +138,10 @@ int agx_phmm_pk_launch_class(int cols_per_lane, bool all_groups_16, bool fast, c
 // cell loop; measured against 26/28/30 in profiles/r01_calibration.log ("striped kernel").
 #define AGX_PH_STRIPE_COLS 24
 #define AGX_PH_FOR_EACH_STRIPE_CLASS(X) X(24)
+// mis_div (with lut_mis = NULL): the mismatch prior is Qr / 3, divided in the step head (GATK prior on reads whose five-column
+// table would not fit the LDS)
 int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
-                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
+                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, int mis_div, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s);
 // float modes: log10(sum) - log10(C) per pair on the device (a negated sum = recomputed in double, scaled by DBL_MAX/16)
 // AGX_PHMM_F64 / F64_FMA on plain DNA (reads of ACGTN, haplotypes of ACGT): the prior comes from the read's LDS table

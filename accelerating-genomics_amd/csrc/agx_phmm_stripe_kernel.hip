@@ -31,7 +31,7 @@ template <int C, bool FMA, bool PROBS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
                   const PhWave *__restrict__ waves, uint32_t n_waves, const double *__restrict__ lut,
-                  const double *__restrict__ lut_mis, double *__restrict__ sums, double *__restrict__ scratch,
+                  const double *__restrict__ lut_mis, int mis_div, double *__restrict__ sums, double *__restrict__ scratch,
                   uint32_t scratch_rows, int negate)
 {
     constexpr int G = 64;
@@ -106,7 +106,7 @@ phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ 
                         inY = in[2u * scratch_rows + idx];
                     }
                     const double q_r = tq[t], q_i = tq[rows + t], q_d = tq[2 * rows + t], q_g = tq[3 * rows + t];
-                    const double q_m = tq[mis_off + t];
+                    const double q_m = mis_div ? q_r / 3.0 : tq[mis_off + t]; // (the host's table: d[c] / 3.0, agx_phmm.cpp build_lut)
                     const uint32_t rc = tc[t];
                     const double pm = 1 - q_r;
                     const double pq = rc == (uint32_t)'N' ? pm : q_m;
@@ -181,7 +181,7 @@ phmm_fill_striped(const uint32_t *__restrict__ img, const PhGroup *__restrict__ 
 
 template <int C, bool FMA, bool PROBS>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves, uint32_t grid,
-           const double *lut, const double *lut_mis, double *sums, double *scratch, uint32_t scratch_rows, int negate,
+           const double *lut, const double *lut_mis, int mis_div, double *sums, double *scratch, uint32_t scratch_rows, int negate,
            size_t lds, hipStream_t s)
 {
     auto k = phmm_fill_striped<C, FMA, PROBS>;
@@ -189,20 +189,20 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, s, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, scratch,
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds, s, img, groups, tabs, waves, n_waves, lut, lut_mis, mis_div, sums, scratch,
                        scratch_rows, negate);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <int C>
 int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves,
-                uint32_t grid, const double *l, const double *lm, double *sums, double *scratch, uint32_t scratch_rows,
+                uint32_t grid, const double *l, const double *lm, int mis_div, double *sums, double *scratch, uint32_t scratch_rows,
                 int negate, size_t lds_bytes, hipStream_t s)
 {
     switch (mode) {
-    case 0: return launch<C, false, false>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
-    case 1: return launch<C, true, false>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
-    case 4: return launch<C, false, true>(img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
+    case 0: return launch<C, false, false>(img, groups, tabs, waves, n_waves, grid, l, lm, mis_div, sums, scratch, scratch_rows, negate, lds_bytes, s);
+    case 1: return launch<C, true, false>(img, groups, tabs, waves, n_waves, grid, l, lm, mis_div, sums, scratch, scratch_rows, negate, lds_bytes, s);
+    case 4: return launch<C, false, true>(img, groups, tabs, waves, n_waves, grid, l, lm, mis_div, sums, scratch, scratch_rows, negate, lds_bytes, s);
     default: return -2;
     }
 }
@@ -210,13 +210,13 @@ int launch_mode(int mode, const uint32_t *img, const PhGroup *groups, const PhTa
 } // namespace
 
 int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
-                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, double *sums, double *scratch,
+                           uint32_t n_waves, uint32_t grid, const void *lut, const void *lut_mis, int mis_div, double *sums, double *scratch,
                            uint32_t scratch_rows, int negate, size_t lds_bytes, hipStream_t s)
 {
     if (n_waves == 0) return 0;
     const double *l = (const double *)lut, *lm = (const double *)lut_mis;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, grid, l, lm, sums, scratch, scratch_rows, negate, lds_bytes, s);
+    case CC: return launch_mode<CC>(mode, img, groups, tabs, waves, n_waves, grid, l, lm, mis_div, sums, scratch, scratch_rows, negate, lds_bytes, s);
     switch (cols_per_lane) {
         AGX_PH_FOR_EACH_STRIPE_CLASS(AGX_PH_CASE)
     default: return -2;

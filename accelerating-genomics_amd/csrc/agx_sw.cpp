@@ -886,7 +886,14 @@ int create_batch(agx_ctx *ctx, const agx_sw_scoring *scoring, const agx_sw_matri
             if (t.joinable()) t.join();
         }
     } joiner{uploader};
-    if (ctx && n_pairs > 0) uploader = std::thread(upload_inputs);
+    if (ctx && n_pairs > 0) {
+        // page-locked arrays (agx_host_alloc) go down without the runtime staging anything: hipMemcpyAsync returns at once,
+        // and the helper thread -- 50 us to start and join, a tenth of a config-2-sized call -- is not needed
+        const bool queued_at_once = !dense_copy && !matrix && agx_is_pinned_host(bases + ext_lo, (size_t)raw_bytes) &&
+                                    agx_is_pinned_host(off, (size_t)n_pairs * 2 * sizeof(uint64_t));
+        if (queued_at_once) upload_inputs();
+        else uploader = std::thread(upload_inputs);
+    }
 
     // one shape in the whole batch?
     int64_t n_fill = 0;

@@ -84,6 +84,10 @@ int agx_ctx_sync(agx_ctx *ctx);
 #define AGX_SW_PLANNER_AUTO 0   /* on the device for large mixed batches of the packed biased fill, else on the host */
 #define AGX_SW_PLANNER_HOST 1   /* always on the host (threaded) */
 #define AGX_SW_PLANNER_DEVICE 2 /* on the device whenever the batch-level rules allow it, whatever the batch size */
+#define AGX_OPT_PHMM_TRAINS 3 /* read trains in the packed float PairHMM fill (AGX_PHMM_F32_FMA); same results bit for bit */
+#define AGX_PHMM_TRAINS_AUTO 0 /* two reads of a region share their lane groups where the batch is large enough for it to pay */
+#define AGX_PHMM_TRAINS_OFF 1  /* every read drains before the next enters (the schedule of rounds 1 and 2) */
+#define AGX_PHMM_TRAINS_ON 2   /* wherever two reads can share a group, whatever the batch size */
 int agx_ctx_set_option(agx_ctx *ctx, int key, int64_t value);
 /* Brings the HIP runtime and the process-wide contexts of these devices up (the ones agx_*_devices / agx_*_multi /
  * agx_pairHMM use) without computing anything: about 0.2 s that a host can spend on another thread while it

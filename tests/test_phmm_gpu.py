@@ -156,6 +156,43 @@ def test_striped_and_single_pass_pairs_in_one_batch(ctx, oracle):
     assert np.array_equal(s, s3)
 
 
+def test_striped_gatk_prior_on_the_longest_reads(ctx, oracle):
+    """Reads beyond 3 870 bases against a striped haplotype under the GATK prior: the five-column read table would take more
+    than the 160 KiB of LDS (AGX_E_LIMIT until round 3), so the striped launch keeps four columns and divides Qr by 3 in
+    its step head -- the results are the five-column table's, bit for bit (checked against the oracle's variant 3; a
+    shorter read rides in the same launch: one batch, one table layout)."""
+    rng = np.random.default_rng(77)
+    hap = synth._ACGT[rng.integers(0, 4, size=4200)].tobytes()
+    reads = []
+    for R in (4096, 3871, 500):
+        src = np.frombuffer(hap, dtype=np.uint8)
+        st = int(rng.integers(0, src.size - R + 1))
+        rd = src[st : st + R].copy()
+        rd[rng.random(R) < 0.02] = ord("N")
+        q = lambda lo, hi: (rng.integers(lo, hi, size=R) + 33).astype(np.uint8).tobytes()
+        reads.append((rd.tobytes(), q(6, 42), q(39, 46), q(39, 46), bytes([43]) * R))
+    hap2 = np.frombuffer(hap, dtype=np.uint8).copy()
+    snp = rng.random(hap2.size) < 0.01
+    hap2[snp] = synth._ACGT[rng.integers(0, 4, size=int(snp.sum()))]
+    hap2 = hap2.tobytes() + synth._ACGT[rng.integers(0, 4, size=300)].tobytes()
+    b = synth.phmm_from_regions([(reads, [hap, hap2])])
+    s3, l3 = oracle.phmm_batch(b, 3)
+    assert np.all(np.isfinite(l3))
+    dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR)
+    dev.launch()
+    l, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, s3) and np.array_equal(l, l3)
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F32_FMA | agx.PHMM_GATK_PRIOR), l3) <= 1e-6
+    # without the prior the four-column table always fitted
+    s0, _ = oracle.phmm_batch(b, 0)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64)
+    dev.launch()
+    _, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, s0)
+
+
 def test_many_striped_pairs_share_the_scratch(ctx, oracle):
     """More long pairs than resident workgroups (8 per CU): every workgroup walks several pairs."""
     b = synth.phmm_regions(3, 40, 20, 12, 2300, seed=9, jitter=4)
@@ -265,6 +302,69 @@ def test_packed_float_cell_variants(ctx, oracle):
         assert np.array_equal(np.isfinite(got), ok)
         d = np.abs(got[ok] - l_ref[ok])
         assert not (d > 1e-6 * np.abs(l_ref[ok])).any()  # relative only: likelihoods near 1 go through the accuracy guard
+
+
+def test_read_trains_change_nothing(ctx, oracle):
+    """AGX_OPT_PHMM_TRAINS: two reads of a region may share their lane groups in the packed float fill (the second enters
+    behind a reset row as the first leaves).  The state behind the reset row is the state a fresh group starts with, so
+    forcing trains on must give the results of the plain schedule BIT FOR BIT -- uniform regions, odd haplotype and read
+    counts, mixed lengths, N in reads, the GATK prior, underflowing pairs (rescue plan), bound results -- and within 1e-6
+    of the oracle."""
+    far = synth.phmm_regions(2, 8, 4, 100, 300, seed=81)
+    far.read_bases[:] = np.frombuffer(b"ACGT", np.uint8)[np.random.default_rng(82).integers(0, 4, far.read_bases.size)]
+    nread = synth.phmm_regions(3, 7, 6, 80, 200, seed=93)
+    nread.read_bases[np.random.default_rng(94).random(nread.read_bases.size) < 0.03] = ord("N")
+    cases = [("uniform", synth.phmm_regions(6, 16, 16, 100, 300, seed=90), agx.PHMM_F32_FMA),
+             ("odd counts", synth.phmm_regions(5, 7, 5, 100, 300, seed=91), agx.PHMM_F32_FMA),
+             ("mixed lengths", synth.phmm_regions(6, 12, 8, 120, 260, seed=92, jitter=60), agx.PHMM_F32_FMA),
+             ("N in reads", nread, agx.PHMM_F32_FMA),
+             ("gatk prior", synth.phmm_regions(4, 8, 6, 100, 300, seed=95), agx.PHMM_F32_FMA | agx.PHMM_GATK_PRIOR),
+             ("long reads", synth.phmm_regions(2, 6, 4, 290, 400, seed=96), agx.PHMM_F32_FMA),
+             ("underflow", far, agx.PHMM_F32_FMA)]
+    waves_off = {}
+    try:
+        for name, p, prec in cases:
+            _, ref = oracle.phmm_batch(p, 3 if prec & agx.PHMM_GATK_PRIOR else 0)
+            res = {}
+            for opt in (agx.PHMM_TRAINS_OFF, agx.PHMM_TRAINS_ON):
+                ctx.set_option(agx.OPT_PHMM_TRAINS, opt)
+                dev = ctx.phmm_batch(p, prec)
+                waves = dev.info().n_waves
+                dev.launch()
+                l, s = dev.results()
+                dev.close()
+                res[opt] = (l, s, waves)
+            l0, s0, w0 = res[agx.PHMM_TRAINS_OFF]
+            waves_off[name] = w0
+            l1, s1, w1 = res[agx.PHMM_TRAINS_ON]
+            assert np.array_equal(s0, s1) and np.array_equal(l0, l1), name
+            if name in ("uniform", "odd counts"):
+                assert w1 < w0, (name, w0, w1)  # trains were formed: fewer waves (mixed regions may need as many, or more)
+            ok = np.isfinite(ref)
+            assert relerr(l1[ok], ref[ok]) <= 1e-6, name
+        # bound results through a train launch
+        ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_ON)
+        p = cases[1][1]
+        dev = ctx.phmm_batch(p, agx.PHMM_F32_FMA)
+        out = agx.host_array(p.n_pairs + 2, np.float64)
+        out[:] = 7.0
+        dev.bind_results(out[:p.n_pairs])
+        dev.launch()
+        dev.results((out[:p.n_pairs], None), want_sums=False)
+        dev.close()
+        ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_OFF)
+        plain = ctx.phmm_forward(p, agx.PHMM_F32_FMA)
+        assert np.array_equal(out[:p.n_pairs], plain) and np.all(out[p.n_pairs:] == 7.0)
+    finally:
+        ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_AUTO)
+    # the default: config 3's shape and size forms trains by itself, small batches do not
+    big = synth.phmm_regions(64, 64, 16, 100, 300, seed=3)
+    dev = ctx.phmm_batch(big, agx.PHMM_F32_FMA)
+    assert dev.info().n_waves == 4096
+    dev.close()
+    small = ctx.phmm_batch(cases[0][1], agx.PHMM_F32_FMA)
+    assert small.info().n_waves == waves_off["uniform"]
+    small.close()
 
 
 def test_degenerate_pairs(ctx, oracle):
