@@ -509,7 +509,11 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             if (b_end - a_end != a_end - a) return;
             for (size_t k = 0; k < a_end - a; ++k)
                 if (plan[a + k].hap != plan[a_end + k].hap) return;
-            if (ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return;
+            // the tables a wave of such groups needs must fit its LDS share: a run that does not fill a wave shares it with
+            // its neighbours' tables (mixed regions), and a train's table is twice a read's
+            const size_t run_groups = (a_end - a + 1) / 2, per_wave = (size_t)(64 / G);
+            const size_t tables = (per_wave + run_groups - 1) / run_groups + (run_groups % per_wave ? 1 : 0);
+            if (tables * ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return;
             run_delta = a_end - a;
         };
         while (i < end) {
@@ -694,6 +698,9 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             use_trains = false;
             build(po);
             keep = (double)with.padded < 0.985 * (double)po.padded;
+            if (trace)
+                fprintf(stderr, "[phmm make_plan kind %d] read trains: %zu waves / %.4g padded cells with, %zu / %.4g without -> %s\n", kind, with.waves.size(),
+                        (double)with.padded, po.waves.size(), (double)po.padded, keep ? "with" : "without");
         }
         if (keep) {
             with.file_order = po.file_order;
