@@ -503,6 +503,9 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             run_end = a_end;
             run_delta = 0;
             if (a_end >= end || plan[a_end].cls != cls || plan[a_end].G != G) return;
+            // (widths 31 and 32 sit at their 256-register cap: the train build spills 15-25 values and gains nothing --
+            // config 5's packed float shard -1.5 %, four times its size +1.6 %, tools/trains_shapes.py)
+            if (trains != 2 && ct.C[cls] > 30) return;
             const uint32_t rd2 = plan[a_end].read;
             size_t b_end = a_end;
             while (b_end < end && plan[b_end].read == rd2 && plan[b_end].cls == cls && plan[b_end].G == G) ++b_end;
