@@ -95,6 +95,13 @@ while time.time() < t_end:
             idx = np.flatnonzero(m)[bad]
             print("f32 family mismatch: pairs (index, R, H, got, ref):", [(int(k), int(Rs[k]), int(Hs[k]), float(got[k]), float(l_ref[k])) for k in idx[:12]], flush=True)
         assert not bad.any(), ("f32 family", prec, float(d[bad].max()), seed, n_ph)
+        if prec == agx.PHMM_F32_FMA:  # read trains forced on: the plain schedule's results bit for bit
+            ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_ON)
+            try:
+                with_trains = ctx.phmm_forward(b, prec)
+            finally:
+                ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_AUTO)
+            assert np.array_equal(with_trains, got, equal_nan=True), ("read trains", seed, n_ph)
     s3, _ = orc.phmm_batch(b, 3)
     dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR); dev.launch(); _, s = dev.results(); dev.close()
     assert np.array_equal(s, s3), ("gatk", seed, n_ph)

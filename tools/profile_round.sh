@@ -19,7 +19,7 @@ def pick(table, *needles):
             return int(round(v["hbm_bytes_corrected"]))
     return None
 commit = open("profiles/.commit").read().strip() if os.path.exists("profiles/.commit") else "unknown"
-out = {"sw_fill": pick(raw, "sw_fill_pk2<38"), "phmm_fill": pick(raw, "phmm_fill_pk_w3<19"), "sw_fill_int32": pick(raw, "sw_fill_i32d") or pick(raw, "sw_fill<"),
+out = {"sw_fill": pick(raw, "sw_fill_pk2<38"), "phmm_fill": pick(raw, "phmm_fill_pk<19, true, true, true") or pick(raw, "phmm_fill_pk_w3<19"), "sw_fill_int32": pick(raw, "sw_fill_i32d") or pick(raw, "sw_fill<"),
        "sw_fill_c4shard": pick(extra, "sw_fill_pk2_any"), "phmm_fill_c5shard": pick(extra, "phmm_fill_lut_w2<32"),
        "sw_pack_dna_c2_and_c4shard_mean": pick(extra, "sw_pack_dna"),
        "_commit": commit,

@@ -33,7 +33,7 @@ for f in glob.glob(os.path.join(d, "kt", "**", "*kernel_trace.csv"), recursive=T
         by[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))].append(
             (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("## kernel durations by launch shape (from the kernel trace; headline launches: sw_fill_pk2<38> with 512 "
-          "workgroups = 2048 waves, phmm_fill_pk_w3<19, true> with 8192; the int32 leg is sw_fill_i32d<38> with 512)\n")
+          "workgroups = 2048 waves, phmm_fill_pk<19, true, true, true> -- config 3 with read trains -- with 4096; the int32 leg is sw_fill_i32d<38> with 512)\n")
     print("| kernel | workgroups | calls | avg us | min us | max us |\n|---|---|---|---|---|---|")
     for (k, wg), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
         if k.startswith("__amd"):
