@@ -515,7 +515,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             // the tables a wave of such groups needs must fit its LDS share: a run that does not fill a wave shares it with
             // its neighbours' tables (mixed regions), and a train's table is twice a read's
             const size_t run_groups = (a_end - a + 1) / 2, per_wave = (size_t)(64 / G);
-            const size_t tables = (per_wave + run_groups - 1) / run_groups + (run_groups % per_wave ? 1 : 0);
+            const size_t tables = trains == 2 ? 1 : (per_wave + run_groups - 1) / run_groups + (run_groups % per_wave ? 1 : 0); // (forced: one table must fit)
             if (tables * ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return;
             run_delta = a_end - a;
         };
