@@ -493,32 +493,34 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
     // +5.4 % on config 3, +5.8 % at four times its size; trains of four +4 %, of eight a loss (their tables outgrow the LDS
     // share of a wave).  Only where the paired waves still fill the chip: from two waves per SIMD after pairing.
     bool use_trains = slots == 2 && trains != 1 && (trains == 2 || waves_est >= 16.0 * n_cu);
+    // the run of entries of plan[a]'s read in its (class, G) bucket ends at run_end; returns how many entries on its partner
+    // run -- the next read, same bucket, same haplotypes -- starts (0: none)
+    auto partner_of = [&](size_t a, const size_t end, size_t &run_end) -> size_t {
+        const uint32_t rd = plan[a].read;
+        const int cls = plan[a].cls, G = plan[a].G;
+        size_t a_end = a;
+        while (a_end < end && plan[a_end].read == rd && plan[a_end].cls == cls && plan[a_end].G == G) ++a_end;
+        run_end = a_end;
+        if (a_end >= end || plan[a_end].cls != cls || plan[a_end].G != G) return 0;
+        // (widths 31 and 32 sit at their 256-register cap: the train build spills 15-25 values and gains nothing --
+        // config 5's packed float shard -1.5 %, four times its size +1.6 %, tools/trains_shapes.py)
+        if (trains != 2 && ct.C[cls] > 30) return 0;
+        const uint32_t rd2 = plan[a_end].read;
+        size_t b_end = a_end;
+        while (b_end < end && plan[b_end].read == rd2 && plan[b_end].cls == cls && plan[b_end].G == G) ++b_end;
+        if (b_end - a_end != a_end - a) return 0;
+        for (size_t k = 0; k < a_end - a; ++k)
+            if (plan[a + k].hap != plan[a_end + k].hap) return 0;
+        // the tables a wave of such groups needs must fit its LDS share: a run that does not fill a wave shares it with
+        // its neighbours' tables (mixed regions), and a train's table is twice a read's
+        const size_t run_groups = (a_end - a + 1) / 2, per_wave = (size_t)(64 / G);
+        const size_t tables = trains == 2 ? 1 : (per_wave + run_groups - 1) / run_groups + (run_groups % per_wave ? 1 : 0); // (forced: one table must fit)
+        if (tables * ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return 0;
+        return a_end - a;
+    };
     auto fill_waves = [&](size_t i, const size_t end, PlanOut &o) {
         size_t run_end = i, run_delta = 0; // the read run i is in ends at run_end; its partner run starts run_delta entries on (0: none)
-        auto find_partner = [&](size_t a) {
-            const uint32_t rd = plan[a].read;
-            const int cls = plan[a].cls, G = plan[a].G;
-            size_t a_end = a;
-            while (a_end < end && plan[a_end].read == rd && plan[a_end].cls == cls && plan[a_end].G == G) ++a_end;
-            run_end = a_end;
-            run_delta = 0;
-            if (a_end >= end || plan[a_end].cls != cls || plan[a_end].G != G) return;
-            // (widths 31 and 32 sit at their 256-register cap: the train build spills 15-25 values and gains nothing --
-            // config 5's packed float shard -1.5 %, four times its size +1.6 %, tools/trains_shapes.py)
-            if (trains != 2 && ct.C[cls] > 30) return;
-            const uint32_t rd2 = plan[a_end].read;
-            size_t b_end = a_end;
-            while (b_end < end && plan[b_end].read == rd2 && plan[b_end].cls == cls && plan[b_end].G == G) ++b_end;
-            if (b_end - a_end != a_end - a) return;
-            for (size_t k = 0; k < a_end - a; ++k)
-                if (plan[a + k].hap != plan[a_end + k].hap) return;
-            // the tables a wave of such groups needs must fit its LDS share: a run that does not fill a wave shares it with
-            // its neighbours' tables (mixed regions), and a train's table is twice a read's
-            const size_t run_groups = (a_end - a + 1) / 2, per_wave = (size_t)(64 / G);
-            const size_t tables = trains == 2 ? 1 : (per_wave + run_groups - 1) / run_groups + (run_groups % per_wave ? 1 : 0); // (forced: one table must fit)
-            if (tables * ph_pk_tab_bytes(plan[a].R + 1u + plan[a_end].R + 2u * ((uint32_t)G - 1u)) > tab_budget()) return;
-            run_delta = a_end - a;
-        };
+        auto find_partner = [&](size_t a) { run_delta = partner_of(a, end, run_end); };
         while (i < end) {
             const int cls = plan[i].cls;
             ClassLaunch cl;
@@ -688,6 +690,10 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
         });
     }
     };
+    // (one shape throughout: every run pairs like the first, and pairing only removes steps -- one plan is made, whichever)
+    size_t probe_end = 0;
+    const bool sure = use_trains && one_shape && !plan.empty() && partner_of(0, plan.size(), probe_end) != 0;
+    if (use_trains && one_shape && !sure && trains != 2) use_trains = false;
     if (use_trains) {
         // Trains double a table: where a wave's groups come from several reads (mixed regions: a read's haplotype pairs do
         // not fill a wave) fewer tables fit the wave's LDS share and lanes stay empty -- on the reference's corpus shape
@@ -696,7 +702,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
         PlanOut with;
         build(with);
         with.trains = true;
-        bool keep = trains == 2;
+        bool keep = trains == 2 || sure;
         if (!keep) {
             use_trains = false;
             build(po);

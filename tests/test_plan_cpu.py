@@ -83,6 +83,25 @@ def test_phmm_plans(prec):
     q.close()
 
 
+def test_packed_float_plans_pair_reads_into_trains_where_it_pays():
+    """Read trains (packed float fill): config 3's 65 536 uniform pairs are planned as 4096 waves of two reads each --
+    2 (R + 1) + G - 2 = 216 steps of 16 lanes x 19 columns x two haplotypes -- mixed regions keep the plain plan when pairing
+    does not reduce the padded cells, small batches and the double modes never pair."""
+    i = agx.PhmmBatchDev(None, synth.phmm_regions(64, 64, 16, 100, 300, seed=3), agx.PHMM_F32_FMA).info()
+    assert i.n_waves == 4096 and i.padded_cells == 4096 * 216 * 64 * 19 * 2
+    assert abs(i.cells / i.padded_cells - 0.9137) < 1e-3
+    # an odd read count: the last read of every region has no partner and fills its groups alone
+    j = agx.PhmmBatchDev(None, synth.phmm_regions(64, 63, 16, 100, 300, seed=3), agx.PHMM_F32_FMA).info()
+    assert j.n_waves == 64 * (31 * 2 + 2) and j.padded_cells == 64 * 2 * (31 * 216 + 115) * 64 * 19 * 2
+    # config 5's shard tiles 16 x 32: the widest builds are left alone
+    k = agx.PhmmBatchDev(None, synth.phmm_regions(32, 64, 16, 250, 500, seed=5), agx.PHMM_F32_FMA).info()
+    assert k.n_waves == 4096
+    small = agx.PhmmBatchDev(None, synth.phmm_regions(4, 64, 16, 100, 300, seed=3), agx.PHMM_F32_FMA).info()
+    assert small.cells / small.padded_cells < 0.87  # no trains below two waves per SIMD
+    d = agx.PhmmBatchDev(None, synth.phmm_regions(64, 64, 16, 100, 300, seed=3), agx.PHMM_F64).info()
+    assert d.cells / d.padded_cells < 0.87
+
+
 def test_substitution_matrix_plans_and_validation():
     """8f n3: agx_sw_batch_create_matrix validates the matrix and the alphabet on the host."""
     m = agx.SwMatrix.build(synth.AMINO, synth.BLOSUM62, -11, -1)
