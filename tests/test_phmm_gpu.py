@@ -367,6 +367,26 @@ def test_read_trains_change_nothing(ctx, oracle):
     small.close()
 
 
+def test_plain_packed_cell_on_a_config3_sized_batch(ctx, oracle):
+    """The plain cell of the packed float fill (one Phred-0 gap-continuation quality in the batch keeps the fast cell out) in
+    the build for 16-lane groups, whose last-row sum is taken behind the loop: config 3's shape and size, the first two
+    regions against the oracle, everything against the fast cell's results of the unmodified batch."""
+    p = synth.phmm_regions(64, 64, 16, 100, 300, seed=11)
+    fast = ctx.phmm_forward(p, agx.PHMM_F32_FMA)
+    q = synth.phmm_regions(64, 64, 16, 100, 300, seed=11)
+    q.q_gcp[int(q.roff[-1]) - 1] = ord("!")  # the last read's last base
+    dev = ctx.phmm_batch(q, agx.PHMM_F32_FMA)
+    assert dev.info().n_waves == 8192  # the plain cell does not pair reads
+    dev.launch()
+    plain, _ = dev.results()
+    dev.close()
+    _, ref = oracle.phmm_batch(q.regions(0, 2), 0)
+    assert relerr(plain[: ref.size], ref) <= 1e-6
+    same = np.ones(p.n_pairs, bool)
+    same[-16:] = False  # the changed read's pairs
+    assert relerr(plain[same], fast[same]) <= 1e-6
+
+
 def test_degenerate_pairs(ctx, oracle):
     b = synth.phmm_from_regions([([(b"", b"", b"", b"", b""), (b"A", b"I", b"I", b"I", b"+")], [b"", b"A", b"ACGT"])])
     got = ctx.phmm_forward(b)
