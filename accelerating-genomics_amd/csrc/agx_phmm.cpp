@@ -1385,7 +1385,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                 const int r = agx_phmm_lut_launch_class(b->precision == AGX_PHMM_F64_FMA, cl.C, cl.all_g16, (const uint32_t *)b->img.p,
                                                         (const PhGroup *)b->main.groups.p, (const PhTab *)b->main.tabs.p,
                                                         (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_d, mis_for_d,
-                                                        (double *)b->sums.p, cl.lds, st);
+                                                        (double *)b->sums.p, cl.lds, !agx_tune("AGX_PHMM_LUT_ONE_LOOP"), st);
                 if (r) {
                     agx_set_error("phmm_fill_lut<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
                     return AGX_E_HIP;

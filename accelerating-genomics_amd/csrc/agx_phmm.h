@@ -147,7 +147,7 @@ int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, con
 // AGX_PHMM_F64 / F64_FMA on plain DNA (reads of ACGTN, haplotypes of ACGT): the prior comes from the read's LDS table
 int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups,
                               const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis,
-                              double *sums, size_t lds_bytes, hipStream_t s);
+                              double *sums, size_t lds_bytes, bool phased, hipStream_t s);
 void agx_phmm_lut_preload();
 void agx_phmm_pk_preload();
 void agx_phmm_scalar_preload();

@@ -59,7 +59,10 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t base, uint32_t packed, int
     return r;
 }
 
-template <int C, bool FMA, bool ROW16>
+// PHASED (round 3, builds for 16-lane groups): the likelihood sum travels down the lanes only while some lane is at its read's last
+// row -- a window of about G steps; the loops before and behind it carry neither the sum's lane shift nor the compare and the
+// summing block (agx_phmm_pk_kernel.inc: the same three loops).
+template <int C, bool FMA, bool ROW16, bool PHASED>
 __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                               const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves, uint32_t n_waves,
                                               const double *__restrict__ lut, const double *__restrict__ lut_mis,
@@ -154,24 +157,25 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
     int trow = 1 - gl;
 
     my_tab += (uint32_t)reinterpret_cast<uintptr_t>((lds_byte *)lds); // from here on an LDS address
-    for (int t = 0; t < steps; ++t, ++trow) {
+    auto one_step = [&](int t, auto sum_tag) __attribute__((always_inline)) {
+        constexpr bool SUM = decltype(sum_tag)::value;
         const uint32_t rowoff = my_tab + (uint32_t)min(max(trow, 0), R + 1) * kRow; // v_med3_i32
         const double q_i = lds_double(rowoff), q_d = lds_double(rowoff + 8), q_g = lds_double(rowoff + 16);
         const double mm = 1 - (q_i + q_d); // mm() (:115-117)
         const double gm = 1 - q_g;
         const uint32_t priors = rowoff + 24u; // (added here: behind the written-out add the compiler would not fold it into the read's offset)
 
-        double lM, lX, lY, acc; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
+        double lM, lX, lY, acc = 0; // left neighbours; column 0 of rows >= 1 is all zeros (:168-178)
         if constexpr (ROW16) {
             lM = rshr1(M[C - 1]);
             lX = rshr1(X[C - 1]);
             lY = rshr1(Y[C - 1]);
-            acc = rshr1(acc_prev);
+            if constexpr (SUM) acc = rshr1(acc_prev);
         } else {
             lM = shr1(M[C - 1]);
             lX = shr1(X[C - 1]);
             lY = shr1(Y[C - 1]);
-            acc = shr1(acc_prev);
+            if constexpr (SUM) acc = shr1(acc_prev);
             if (start) {
                 lM = 0;
                 lX = 0;
@@ -205,50 +209,69 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
             cY = y;
             Y[j] = y;
         }
-        if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
-            if (col0 + C <= H) {
+        if constexpr (SUM) {
+            if (t - gl + 1 == R) { // last read row: likelihood (:206-212), columns in order
+                if (col0 + C <= H) {
 #pragma unroll
-                for (int j = 0; j < C; ++j) acc += (M[j] + X[j]);
-            } else {
+                    for (int j = 0; j < C; ++j) acc += (M[j] + X[j]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < C; ++j)
-                    if (col0 + j < H) acc += (M[j] + X[j]);
+                    for (int j = 0; j < C; ++j)
+                        if (col0 + j < H) acc += (M[j] + X[j]);
+                }
+                if (gl == G - 1) result = acc;
             }
-            if (gl == G - 1) result = acc;
+            acc_prev = acc;
         }
-        acc_prev = acc;
-    }
+        ++trow;
+    };
+    if constexpr (PHASED) {
+        // wave-uniform window of the steps in which some lane is at its read's last row (inactive lanes: R = 0, none)
+        int lo = active ? R + gl - 1 : 0x7fffffff, hi = active ? R + gl - 1 : -1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo = min(lo, __shfl_xor(lo, d));
+            hi = max(hi, __shfl_xor(hi, d));
+        }
+        lo = min(__builtin_amdgcn_readfirstlane(lo), steps);
+        hi = min(__builtin_amdgcn_readfirstlane(hi) + 1, steps);
+        int t = 0;
+        for (; t < lo; ++t) one_step(t, std::false_type{});
+        for (; t < hi; ++t) one_step(t, std::true_type{});
+        for (; t < steps; ++t) one_step(t, std::false_type{});
+    } else
+        for (int t = 0; t < steps; ++t) one_step(t, std::true_type{});
     if (active && gl == G - 1) sums[g.out] = result;
 }
 
-template <int C, bool FMA, bool ROW16>
+template <int C, bool FMA, bool ROW16, bool PHASED>
 __global__ void __launch_bounds__(64) phmm_fill_lut(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                                     const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                     uint32_t n_waves, const double *__restrict__ lut,
                                                     const double *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_lut_body<C, FMA, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_lut_body<C, FMA, ROW16, PHASED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
 // the widest classes asked to fit two waves per SIMD (256 VGPRs), as phmm_fill_w2 in agx_phmm_kernel.hip
-template <int C, bool FMA, bool ROW16>
+template <int C, bool FMA, bool ROW16, bool PHASED>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_lut_w2(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
                  const PhWave *__restrict__ waves, uint32_t n_waves, const double *__restrict__ lut,
                  const double *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_lut_body<C, FMA, ROW16>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_lut_body<C, FMA, ROW16, PHASED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
-template <int C, bool FMA, bool ROW16>
+template <int C, bool FMA, bool ROW16, bool PHASED>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut,
            const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
     void (*k)(const uint32_t *, const PhGroup *, const PhTab *, const PhWave *, uint32_t, const double *, const double *, double *);
-    if constexpr (C >= AGX_PH_LUT_W2_FROM)
-        k = phmm_fill_lut_w2<C, FMA, ROW16>;
+    if constexpr (C >= AGX_PH_LUT_W2_FROM || (PHASED && C >= 22)) // (the three-loop builds from 22 columns on: 218-276 registers left alone)
+        k = phmm_fill_lut_w2<C, FMA, ROW16, PHASED>;
     else
-        k = phmm_fill_lut<C, FMA, ROW16>;
+        k = phmm_fill_lut<C, FMA, ROW16, PHASED>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
@@ -259,18 +282,24 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
 }
 
 template <int C>
-int launch_mode(bool fma, bool all_g16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+int launch_mode(bool fma, bool all_g16, bool phased, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
                 uint32_t n_waves, const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
     if constexpr (C > 32)
         return -2; // double classes end at 32 columns per lane
     else {
         if (fma) {
-            if (all_g16) return launch<C, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
-            return launch<C, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+            if (all_g16) return launch<C, true, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+            return launch<C, true, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
         }
-        if (all_g16) return launch<C, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
-        return launch<C, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+        // Three loops where they were measured to pay (tools/lut_loops.sh, profiles/r03ap_lut_loops.log): config 5's tiling, 16 lanes
+        // x 32 columns in the reference's operation order, 1.610 -> 1.589 ms; with explicit fma the same build LOSES 3 %
+        // (1.214 -> 1.254 ms), at 30 columns 0.7 % / 3 %, narrower widths do not move.
+        if constexpr (C == 32) {
+            if (all_g16 && phased) return launch<C, false, true, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+        }
+        if (all_g16) return launch<C, false, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+        return launch<C, false, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
     }
 }
 
@@ -278,11 +307,11 @@ int launch_mode(bool fma, bool all_g16, const uint32_t *img, const PhGroup *grou
 
 int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups,
                               const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis,
-                              double *sums, size_t lds_bytes, hipStream_t s)
+                              double *sums, size_t lds_bytes, bool phased, hipStream_t s)
 {
     if (n_waves == 0) return 0;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(fma, all_groups_16, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
+    case CC: return launch_mode<CC>(fma, all_groups_16, phased, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
     switch (cols_per_lane) {
         AGX_PH_FOR_EACH_CLASS(AGX_PH_CASE)
     default: return -2;
@@ -294,5 +323,5 @@ int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, c
 void agx_phmm_lut_preload()
 {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_lut<16, false, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_lut<16, false, false, false>));
 }
