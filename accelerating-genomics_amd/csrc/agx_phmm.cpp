@@ -1059,11 +1059,14 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // A packed float batch cannot reuse its records for the double rescue pass: that pass has a plan of its own, made
     // from the kept seed when a fill first counts a pair below the float range (ensure_rescue_plan).
     // double modes on plain DNA run the kernel whose read tables carry the priors (other rows, other LDS sizes)
-    // (... while the longest read's table stays below 40 KB -- 730 rows: beyond that the 33-byte rows of phmm_fill keep
-    // more waves on a CU, and a 4096-row read fits the 160 KB only there)
+    // (... while the longest read's table stays within a wave's LDS share when two waves per SIMD are resident -- 20 KB, 363
+    // rows of 56 bytes: a launch reserves its longest table for every wave, so beyond that fewer waves fit a CU and the
+    // 33-byte rows of phmm_fill win -- 7 % at reads of 420 bases, 19 % at 500, 20 % at 600 -- although that kernel selects
+    // its priors (tools/lut_vs_select_long_reads.py, profiles/r03as_lut_vs_select.log; the limit was 40 KB until round 3);
+    // a 4096-row read fits the 160 KB only there)
     uint64_t longest_read = 0;
     for (uint32_t r = 0; r < n_reads; ++r) longest_read = std::max<uint64_t>(longest_read, d->read_off[r + 1] - d->read_off[r]);
-    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && ph_lut_tab_bytes((uint32_t)longest_read + 2u) <= 40u * 1024u &&
+    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && ph_lut_tab_bytes((uint32_t)longest_read + 2u) <= 20u * 1024u &&
                            !agx_tune("AGX_PHMM_NO_LUT");
     const size_t n_work = gen0.size(); // pairs with work (every pair of the batch, unless a read or haplotype is empty)
     PlanOut pmain;
