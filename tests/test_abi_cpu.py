@@ -418,3 +418,14 @@ def test_one_shot_sw_read_of_a_file_beyond_64_mb(tmp_path):
         assert np.array_equal(cb.len.astype(np.int64), lens[2 * total : 2 * (total + cb.n_pairs)] + 1)
         total += cb.n_pairs
     assert total == n_lines // 2
+
+
+def test_every_tuning_knob_is_listed():
+    """The tuning build's knobs (agx_tune("...") in the host sources) are the names api.TUNING_KNOBS selects that build by: a knob
+    missing from the list would be set on a process that then loads the shipped library, which reads no environment."""
+    import glob, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accelerating-genomics_amd", "csrc")
+    names = set()
+    for f in glob.glob(os.path.join(root, "*.cpp")):
+        names |= set(re.findall(r'agx_tune\("([A-Z0-9_]+)"\)', open(f).read()))
+    assert names and names <= set(agx.TUNING_KNOBS), sorted(names - set(agx.TUNING_KNOBS))
