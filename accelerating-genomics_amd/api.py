@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # only (libagx_tuning.so, -DAGX_TUNING): a process that sets one of them gets that library.
 TUNING_KNOBS = ("AGX_SW_KERNEL", "AGX_SW_TAIL_BETA", "AGX_SW_MAX_C", "AGX_SW_FORCE_C", "AGX_SW_MAX_CLASSES", "AGX_SW_WAVES_PER_CLASS",
                 "AGX_SW_SORT_WAVES", "AGX_SW_ONE_LAUNCH", "AGX_SW_DNA", "AGX_SW_RISE", "AGX_PHMM_PLAIN_CELL", "AGX_TRACE_CREATE", "AGX_HOST_THREADS", "AGX_FANOUT", "AGX_PHMM_TAB_BUDGET", "AGX_PHMM_MAX_C",
-                "AGX_PHMM_FORCE_C", "AGX_PHMM_TAIL_BETA", "AGX_PHMM_MAX_CLASSES", "AGX_PHMM_NO_LUT", "AGX_TRACE_POOL", "AGX_NO_STREAM_PRIO", "AGX_SW_I32_CLASSIC", "AGX_SW_PIECE_MB", "AGX_SW_PIECE_MIN_PAIRS", "AGX_PHMM_NO_ROWS", "AGX_PHMM_NO_TRAINS", "AGX_PHMM_LUT_ONE_LOOP", "AGX_SW_HOST_PLAN")
+                "AGX_PHMM_FORCE_C", "AGX_PHMM_TAIL_BETA", "AGX_PHMM_MAX_CLASSES", "AGX_PHMM_NO_LUT", "AGX_TRACE_POOL", "AGX_NO_STREAM_PRIO", "AGX_SW_I32_CLASSIC", "AGX_SW_PIECE_MB", "AGX_SW_PIECE_MIN_PAIRS", "AGX_PHMM_NO_ROWS", "AGX_PHMM_NO_TRAINS", "AGX_PHMM_LUT_ONE_LOOP", "AGX_SW_HOST_PLAN", "AGX_PHMM_NO_RING")
 _DEFAULT_LIB = "libagx_tuning.so" if any(k in os.environ for k in TUNING_KNOBS) else "libagx.so"
 LIB_PATH = os.environ.get("AGX_LIB_PATH", os.path.join(_HERE, _DEFAULT_LIB))  # override: kernel experiments only
 

@@ -544,14 +544,14 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                     const uint32_t nsteps = std::max(steps, p.R + (tr ? R2 + 1u : 0u) + (uint32_t)G - 1u);
                     const uint32_t ntabs_new = ntabs + (p.read != last_read ? 1u : 0u);
                     if (lut_rows) {
-                        if (cnt > 0 && p.read != last_read && lut_bytes + ph_lut_tab_bytes(p.R + 2u) > tab_budget()) break;
+                        if (cnt > 0 && p.read != last_read && lut_bytes + ph_lut_lds_bytes(p.R + 2u) > tab_budget()) break;
                     } else if (cnt > 0 && ntabs_new > 1 && tab_bytes(rows_f64, nsteps + G - 1) * ntabs_new > tab_budget())
                         break;
                     if (p.read != last_read) {
                         // (lut_rows: the table's offset / 16 rides in the upper half of R, agx_phmm_lut_kernel.hip)
                         o.tabs.push_back(PhTab{read_dw[p.read], lut_rows ? p.R | (uint32_t)(lut_bytes / 16) << 16 : p.R});
                         if (use_trains) o.tabs.push_back(tr ? PhTab{read_dw[plan[i + tr].read], R2} : PhTab{0u, 0u});
-                        if (lut_rows) lut_bytes += ph_lut_tab_bytes(p.R + 2u);
+                        if (lut_rows) lut_bytes += ph_lut_lds_bytes(p.R + 2u);
                         last_read = p.read;
                     }
                     ntabs = ntabs_new;
@@ -624,7 +624,7 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
                 }
                 if (G != 16) cl.all_g16 = false;
                 cl.lds = std::max(cl.lds, lut_rows ? lut_bytes : tab_bytes(rows_f64, steps + G - 1) * ntabs);
-                cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs);
+                if (kind == 2) cl.lds_rescue = std::max(cl.lds_rescue, ph_tab_bytes(true, gatk_prior, steps + G - 1) * ntabs); // (only the float fill's records are reused for a double pass)
                 o.padded += (int64_t)steps * 64 * cl.C * slots;
                 o.waves.push_back(w);
             }
@@ -762,6 +762,7 @@ struct agx_phmm_batch {
                                   // agx_phmm_batch_results, and only when the fill counted a pair below the float range)
     bool trains = false;          // ... with read trains (PlanOut::trains)
     bool fast = false;            // ... and its fill runs the fast cell (plain DNA, no Phred-0 gap-continuation quality in the batch)
+    bool lut_ring = false;        // ... and some read's table is a ring (ph_lut_is_ring): the STREAM builds
     bool lut_prior = false;       // double modes on plain DNA: priors looked up in the read tables (agx_phmm_lut_kernel.hip)
     bool separate_rescue = false; // the double rescue pass has its own plan (packed batches), made on first use from:
     std::unique_ptr<PlanSeed> rescue_seed;
@@ -1066,8 +1067,10 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     // a 4096-row read fits the 160 KB only there)
     uint64_t longest_read = 0;
     for (uint32_t r = 0; r < n_reads; ++r) longest_read = std::max<uint64_t>(longest_read, d->read_off[r + 1] - d->read_off[r]);
-    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && ph_lut_tab_bytes((uint32_t)longest_read + 2u) <= 20u * 1024u &&
-                           !agx_tune("AGX_PHMM_NO_LUT");
+    // (round 3, second step: such reads keep a 256-row ring in LDS, refilled as the wave advances -- the looked-up-prior kernel
+    // for every read length; AGX_PHMM_NO_RING in the tuning build restores the 20 KB rule)
+    const bool lut_ring = ph_lut_is_ring((uint32_t)longest_read + 2u);
+    const bool lut_prior = f64 && !probs && have_tracks && !not_dna.load() && (!lut_ring || !agx_tune("AGX_PHMM_NO_RING")) && !agx_tune("AGX_PHMM_NO_LUT");
     const size_t n_work = gen0.size(); // pairs with work (every pair of the batch, unless a read or haplotype is empty)
     PlanOut pmain;
     // read trains: the fast cell only, and only on qualities that are probabilities (a byte below '!' is a "probability"
@@ -1139,6 +1142,7 @@ int create_batch(agx_ctx *ctx, const agx_phmm_desc *d, const double *const prob[
     b->fast = packed && !not_fast.load() && !agx_tune("AGX_PHMM_PLAIN_CELL");
     b->trains = packed && pmain.trains;
     b->lut_prior = lut_prior;
+    b->lut_ring = lut_prior && lut_ring;
     // the code objects this batch will launch from, loaded now rather than inside its first launch
     if (ctx) {
         if (packed) agx_phmm_pk_preload();
@@ -1388,7 +1392,7 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
                 const int r = agx_phmm_lut_launch_class(b->precision == AGX_PHMM_F64_FMA, cl.C, cl.all_g16, (const uint32_t *)b->img.p,
                                                         (const PhGroup *)b->main.groups.p, (const PhTab *)b->main.tabs.p,
                                                         (const PhWave *)b->main.waves.p + cl.first_wave, cl.n_waves, lut_d, mis_for_d,
-                                                        (double *)b->sums.p, cl.lds, !agx_tune("AGX_PHMM_LUT_ONE_LOOP"), st);
+                                                        (double *)b->sums.p, cl.lds, !agx_tune("AGX_PHMM_LUT_ONE_LOOP"), b->lut_ring, st);
                 if (r) {
                     agx_set_error("phmm_fill_lut<C=%d> launch failed: %s", cl.C, hipGetErrorString(hipGetLastError()));
                     return AGX_E_HIP;

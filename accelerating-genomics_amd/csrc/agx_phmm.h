@@ -92,6 +92,13 @@ __host__ __device__ static inline size_t ph_tab_bytes(bool f64, bool mis_col, ui
 #define AGX_PH_LUT_ROW_BYTES 56u
 #define AGX_PH_LUT_W2_FROM 32 /* widths from here on are built for two waves per SIMD */
 __host__ __device__ static inline size_t ph_lut_tab_bytes(uint32_t rows) { return ((size_t)rows * AGX_PH_LUT_ROW_BYTES + 15u) & ~(size_t)15u; }
+// Reads whose table would exceed a wave's LDS share at two waves per SIMD (20 KB = 365 rows) keep a RING of 256 rows instead
+// (round 3, STREAM in agx_phmm_lut_kernel.hip): a wave only ever needs the rows behind its current step, the ring is refilled
+// 64 rows at a time.  rows = the read's R + 2.
+#define AGX_PH_LUT_FULL_ROWS 365u
+#define AGX_PH_LUT_RING_ROWS 256u
+__host__ __device__ static inline bool ph_lut_is_ring(uint32_t rows) { return rows > AGX_PH_LUT_FULL_ROWS; }
+__host__ __device__ static inline size_t ph_lut_lds_bytes(uint32_t rows) { return ph_lut_tab_bytes(ph_lut_is_ring(rows) ? AGX_PH_LUT_RING_ROWS : rows); }
 // the packed float kernel's tables: one 32-byte row of derived values per read position
 __host__ __device__ static inline size_t ph_pk_tab_bytes(uint32_t rows) { return (size_t)rows * 32u; }
 
@@ -147,7 +154,7 @@ int agx_phmm_stripe_launch(int mode, int cols_per_lane, const uint32_t *img, con
 // AGX_PHMM_F64 / F64_FMA on plain DNA (reads of ACGTN, haplotypes of ACGT): the prior comes from the read's LDS table
 int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups,
                               const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis,
-                              double *sums, size_t lds_bytes, bool phased, hipStream_t s);
+                              double *sums, size_t lds_bytes, bool phased, bool stream, hipStream_t s);
 void agx_phmm_lut_preload();
 void agx_phmm_pk_preload();
 void agx_phmm_scalar_preload();

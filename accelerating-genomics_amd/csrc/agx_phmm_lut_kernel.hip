@@ -62,7 +62,11 @@ __device__ __forceinline__ uint32_t add_byte(uint32_t base, uint32_t packed, int
 // PHASED (round 3, builds for 16-lane groups): the likelihood sum travels down the lanes only while some lane is at its read's last
 // row -- a window of about G steps; the loops before and behind it carry neither the sum's lane shift nor the compare and the
 // summing block (agx_phmm_pk_kernel.inc: the same three loops).
-template <int C, bool FMA, bool ROW16, bool PHASED>
+// STREAM (round 3): a read whose table would take more than a wave's LDS share (ph_lut_is_ring: more than 365 rows) keeps a ring
+// of 256 rows: rows 0 ... 255 at the start, and in step 64 k + 62 the 64 rows of half k + 3 replace those of half k - 1, which no
+// lane can reach any more (a lane is at most 63 rows behind the wave's first).  One wave per workgroup: LDS operations stay in
+// program order, no barrier.  Tables of shorter reads in the same launch are whole, as without STREAM.
+template <int C, bool FMA, bool ROW16, bool PHASED, bool STREAM>
 __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                               const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves, uint32_t n_waves,
                                               const double *__restrict__ lut, const double *__restrict__ lut_mis,
@@ -90,41 +94,51 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
 
     // ---- read tables -> LDS
     uint32_t my_tab = 0; // byte offset of this group's table
+    uint32_t my_mask = 0xffffffffu; // STREAM: 255 when this group's table is a ring
+    // table row `row` (0 and R + 1: neutral) of the read behind tb, written to slot `slot` of its table
+    auto build_row = [&](const PhTab tb, uint32_t tab_off, uint32_t row, uint32_t slot) __attribute__((always_inline)) {
+        double *tq = reinterpret_cast<double *>(lds + tab_off);
+        const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
+        const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
+        const int i = (int)row - 1;
+        double vi = 0, vd = 0, vg = 1, e0 = 0, e1 = 0, e2 = 0, e3 = 0; // neutral row
+        if (i >= 0 && i < (int)tb.R) {
+            const uint32_t c = rp[i];
+            const double qr = lut[rp[trk + i]];
+            const double pm = 1 - qr;                                  // p(): match or N (:111-113)
+            const double pq = lut_mis ? lut_mis[rp[trk + i]] : qr;     //      mismatch (Qr/3: AGX_PHMM_GATK_PRIOR)
+            vi = lut[rp[2 * trk + i]];
+            vd = lut[rp[3 * trk + i]];
+            vg = lut[rp[4 * trk + i]];
+            const bool any = c == (uint32_t)'N';
+            const uint32_t rc = (c >> 1) & 3u; // A 0, C 1, T 2, G 3
+            e0 = any || rc == 0u ? pm : pq;
+            e1 = any || rc == 1u ? pm : pq;
+            e2 = any || rc == 2u ? pm : pq;
+            e3 = any || rc == 3u ? pm : pq;
+        }
+        double *out = tq + 7u * slot;
+        out[0] = vi;
+        out[1] = vd;
+        out[2] = vg;
+        out[3] = e0;
+        out[4] = e1;
+        out[5] = e2;
+        out[6] = e3;
+    };
+    bool any_ring = false; // wave-uniform
     for (uint32_t k = 0; k < w.n_tabs; ++k) {
         PhTab tb = tabs[w.first_tab + k];
         const uint32_t tab_off = (tb.R >> 16) * 16u;
         tb.R &= 0xffffu;
-        if (k == (g.R_tab >> 16)) my_tab = tab_off;
-        double *tq = reinterpret_cast<double *>(lds + tab_off);
-        const unsigned char *rp = reinterpret_cast<const unsigned char *>(img + tb.read_dw);
-        const uint32_t trk = ((tb.R + 3u) >> 2) * 4u; // bytes per track
-        for (uint32_t r = lane; r < tb.R + 2u; r += 64) {
-            const int i = (int)r - 1;
-            double vi = 0, vd = 0, vg = 1, e0 = 0, e1 = 0, e2 = 0, e3 = 0; // neutral row
-            if (i >= 0 && i < (int)tb.R) {
-                const uint32_t c = rp[i];
-                const double qr = lut[rp[trk + i]];
-                const double pm = 1 - qr;                                  // p(): match or N (:111-113)
-                const double pq = lut_mis ? lut_mis[rp[trk + i]] : qr;     //      mismatch (Qr/3: AGX_PHMM_GATK_PRIOR)
-                vi = lut[rp[2 * trk + i]];
-                vd = lut[rp[3 * trk + i]];
-                vg = lut[rp[4 * trk + i]];
-                const bool any = c == (uint32_t)'N';
-                const uint32_t rc = (c >> 1) & 3u; // A 0, C 1, T 2, G 3
-                e0 = any || rc == 0u ? pm : pq;
-                e1 = any || rc == 1u ? pm : pq;
-                e2 = any || rc == 2u ? pm : pq;
-                e3 = any || rc == 3u ? pm : pq;
-            }
-            double *row = tq + 7u * r;
-            row[0] = vi;
-            row[1] = vd;
-            row[2] = vg;
-            row[3] = e0;
-            row[4] = e1;
-            row[5] = e2;
-            row[6] = e3;
+        const bool ring = STREAM && ph_lut_is_ring(tb.R + 2u);
+        any_ring = any_ring || ring;
+        if (k == (g.R_tab >> 16)) {
+            my_tab = tab_off;
+            if (ring) my_mask = AGX_PH_LUT_RING_ROWS - 1u;
         }
+        const uint32_t rows_now = ring ? AGX_PH_LUT_RING_ROWS : tb.R + 2u;
+        for (uint32_t r = lane; r < rows_now; r += 64) build_row(tb, tab_off, r, r);
     }
     __syncthreads();
 
@@ -159,7 +173,20 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
     my_tab += (uint32_t)reinterpret_cast<uintptr_t>((lds_byte *)lds); // from here on an LDS address
     auto one_step = [&](int t, auto sum_tag) __attribute__((always_inline)) {
         constexpr bool SUM = decltype(sum_tag)::value;
-        const uint32_t rowoff = my_tab + (uint32_t)min(max(trow, 0), R + 1) * kRow; // v_med3_i32
+        if constexpr (STREAM) {
+            if (any_ring && (t & 63) == 62) { // (scalar condition) half (t >> 6) + 3 of every ring: one row per lane
+                const uint32_t row = ((uint32_t)(t >> 6) + 3u) * 64u + (uint32_t)lane;
+                for (uint32_t k = 0; k < w.n_tabs; ++k) {
+                    PhTab tb = tabs[w.first_tab + k];
+                    const uint32_t tab_off = (tb.R >> 16) * 16u;
+                    tb.R &= 0xffffu;
+                    if (ph_lut_is_ring(tb.R + 2u) && row <= tb.R + 1u) build_row(tb, tab_off, row, row & (AGX_PH_LUT_RING_ROWS - 1u));
+                }
+            }
+        }
+        uint32_t rowidx = (uint32_t)min(max(trow, 0), R + 1); // v_med3_i32
+        if constexpr (STREAM) rowidx &= my_mask;
+        const uint32_t rowoff = my_tab + rowidx * kRow;
         const double q_i = lds_double(rowoff), q_d = lds_double(rowoff + 8), q_g = lds_double(rowoff + 16);
         const double mm = 1 - (q_i + q_d); // mm() (:115-117)
         const double gm = 1 - q_g;
@@ -244,34 +271,34 @@ __device__ __forceinline__ void phmm_lut_body(const uint32_t *__restrict__ img, 
     if (active && gl == G - 1) sums[g.out] = result;
 }
 
-template <int C, bool FMA, bool ROW16, bool PHASED>
+template <int C, bool FMA, bool ROW16, bool PHASED, bool STREAM>
 __global__ void __launch_bounds__(64) phmm_fill_lut(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups,
                                                     const PhTab *__restrict__ tabs, const PhWave *__restrict__ waves,
                                                     uint32_t n_waves, const double *__restrict__ lut,
                                                     const double *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_lut_body<C, FMA, ROW16, PHASED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_lut_body<C, FMA, ROW16, PHASED, STREAM>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
 // the widest classes asked to fit two waves per SIMD (256 VGPRs), as phmm_fill_w2 in agx_phmm_kernel.hip
-template <int C, bool FMA, bool ROW16, bool PHASED>
+template <int C, bool FMA, bool ROW16, bool PHASED, bool STREAM>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 phmm_fill_lut_w2(const uint32_t *__restrict__ img, const PhGroup *__restrict__ groups, const PhTab *__restrict__ tabs,
                  const PhWave *__restrict__ waves, uint32_t n_waves, const double *__restrict__ lut,
                  const double *__restrict__ lut_mis, double *__restrict__ sums)
 {
-    phmm_lut_body<C, FMA, ROW16, PHASED>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
+    phmm_lut_body<C, FMA, ROW16, PHASED, STREAM>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums);
 }
 
-template <int C, bool FMA, bool ROW16, bool PHASED>
+template <int C, bool FMA, bool ROW16, bool PHASED, bool STREAM = false>
 int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut,
            const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
     void (*k)(const uint32_t *, const PhGroup *, const PhTab *, const PhWave *, uint32_t, const double *, const double *, double *);
     if constexpr (C >= AGX_PH_LUT_W2_FROM || (PHASED && C >= 22)) // (the three-loop builds from 22 columns on: 218-276 registers left alone)
-        k = phmm_fill_lut_w2<C, FMA, ROW16, PHASED>;
+        k = phmm_fill_lut_w2<C, FMA, ROW16, PHASED, STREAM>;
     else
-        k = phmm_fill_lut<C, FMA, ROW16, PHASED>;
+        k = phmm_fill_lut<C, FMA, ROW16, PHASED, STREAM>;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -1;
@@ -282,12 +309,16 @@ int launch(const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const 
 }
 
 template <int C>
-int launch_mode(bool fma, bool all_g16, bool phased, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
+int launch_mode(bool fma, bool all_g16, bool phased, bool stream, const uint32_t *img, const PhGroup *groups, const PhTab *tabs, const PhWave *waves,
                 uint32_t n_waves, const void *lut, const void *lut_mis, double *sums, size_t lds, hipStream_t s)
 {
     if constexpr (C > 32)
         return -2; // double classes end at 32 columns per lane
     else {
+        if (stream) { // (long reads: the builds for groups of any width serve 16-lane groups too)
+            if (fma) return launch<C, true, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+            return launch<C, false, false, false, true>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
+        }
         if (fma) {
             if (all_g16) return launch<C, true, true, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
             return launch<C, true, false, false>(img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds, s);
@@ -307,11 +338,11 @@ int launch_mode(bool fma, bool all_g16, bool phased, const uint32_t *img, const 
 
 int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups,
                               const PhTab *tabs, const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis,
-                              double *sums, size_t lds_bytes, bool phased, hipStream_t s)
+                              double *sums, size_t lds_bytes, bool phased, bool stream, hipStream_t s)
 {
     if (n_waves == 0) return 0;
 #define AGX_PH_CASE(CC) \
-    case CC: return launch_mode<CC>(fma, all_groups_16, phased, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
+    case CC: return launch_mode<CC>(fma, all_groups_16, phased, stream, img, groups, tabs, waves, n_waves, lut, lut_mis, sums, lds_bytes, s);
     switch (cols_per_lane) {
         AGX_PH_FOR_EACH_CLASS(AGX_PH_CASE)
     default: return -2;
@@ -323,5 +354,5 @@ int agx_phmm_lut_launch_class(bool fma, int cols_per_lane, bool all_groups_16, c
 void agx_phmm_lut_preload()
 {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_lut<16, false, false, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&phmm_fill_lut<16, false, false, false, false>));
 }

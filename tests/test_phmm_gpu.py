@@ -193,6 +193,49 @@ def test_striped_gatk_prior_on_the_longest_reads(ctx, oracle):
     assert np.array_equal(s, s0)
 
 
+def test_long_reads_keep_a_ring_of_table_rows(ctx, oracle):
+    """Reads beyond 363 bases in the double modes: the looked-up-prior kernel keeps a ring of 256 table rows in LDS and refills
+    it 64 rows at a time as the wave advances (a whole table would take more than a wave's LDS share).  Ring and whole
+    tables in one launch, reads up to the 4096-base limit, every row of the ring reused many times: sums bit for bit against
+    the oracle; the GATK prior on a 4096-base read, which no other kernel's table could hold beside a single-pass haplotype."""
+    rng = np.random.default_rng(404)
+    hap_lens = [600, 590, 333, 37]
+    haps = [synth._ACGT[rng.integers(0, 4, size=n)].tobytes() for n in hap_lens]
+    long_hap = synth._ACGT[rng.integers(0, 4, size=2000)].tobytes()
+    reads = []
+    for R in (4096, 2500, 1000, 500, 366, 365, 364, 300, 120, 64, 7):
+        src = np.frombuffer(long_hap * 3, dtype=np.uint8)
+        st = int(rng.integers(0, src.size - R + 1))
+        rd = src[st : st + R].copy()
+        rd[rng.random(R) < 0.02] = ord("N")
+        q = lambda lo, hi: (rng.integers(lo, hi, size=R) + 33).astype(np.uint8).tobytes()
+        reads.append((rd.tobytes(), q(6, 42), q(39, 46), q(39, 46), bytes([43]) * R))
+    b = synth.phmm_from_regions([(reads, haps + [long_hap[:1900]])])
+    s_ref, l_ref = oracle.phmm_batch(b, 0)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64)
+    dev.launch()
+    dev.launch()
+    l, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, s_ref) and np.array_equal(l, l_ref)
+    ok = np.isfinite(l_ref)
+    assert relerr(ctx.phmm_forward(b, agx.PHMM_F64_FMA)[ok], l_ref[ok]) <= 1e-12
+    s3, _ = oracle.phmm_batch(b, 3)
+    dev = ctx.phmm_batch(b, agx.PHMM_F64 | agx.PHMM_GATK_PRIOR)
+    dev.launch()
+    _, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, s3)
+    # uniform long reads fill whole waves of ring tables
+    u = synth.phmm_regions(3, 6, 8, 900, 1000, seed=405)
+    su, _ = oracle.phmm_batch(u, 0)
+    dev = ctx.phmm_batch(u, agx.PHMM_F64)
+    dev.launch()
+    _, s = dev.results()
+    dev.close()
+    assert np.array_equal(s, su)
+
+
 def test_many_striped_pairs_share_the_scratch(ctx, oracle):
     """More long pairs than resident workgroups (8 per CU): every workgroup walks several pairs."""
     b = synth.phmm_regions(3, 40, 20, 12, 2300, seed=9, jitter=4)

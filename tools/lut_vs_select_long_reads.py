@@ -4,8 +4,8 @@
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import accelerating_genomics_amd.api as agx, accelerating_genomics_amd.synth as synth
 ctx = agx.Context(0)
-tag = "selecting (33-byte rows)" if "AGX_PHMM_NO_LUT" in os.environ else "looked up (56-byte rows)"
-for R in (250, 300, 360, 420, 500, 600, 700):
+tag = "selecting (33-byte rows)     " if "AGX_PHMM_NO_LUT" in os.environ else "looked up, whole tables      " if "AGX_PHMM_NO_RING_FORCE_LUT" in os.environ else "looked up, ring of 256 rows  "
+for R in (250, 360, 420, 500, 600, 700):
     p = synth.phmm_regions(16, 64, 16, R, 704, seed=3)
     dev = ctx.phmm_batch(p, agx.PHMM_F64); i = dev.info()
     dev.launch(); ctx.sync(); best = 1e9
