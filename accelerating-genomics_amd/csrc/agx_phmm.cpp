@@ -768,6 +768,7 @@ struct agx_phmm_batch {
     std::unique_ptr<PlanSeed> rescue_seed;
     bool rescue_broken = false; // making that plan failed (out of memory): the batch's float results cannot be completed
     DevBuf img, sums, lut, counter;
+    bool counters_dirty = false; // a launch has counted into `counter` and nobody has taken (and reset) the counts yet
     PinBuf out_stage; // page-locked landing block of the results, taken at create (agx_phmm_batch_results allocates nothing)
     struct DevPlan {
         DevBuf groups, tabs, waves;
@@ -1334,7 +1335,11 @@ int agx_phmm_batch_launch(agx_phmm_batch *b)
     const void *mis_d = (const char *)b->lut.p + 256 * (sizeof(double) + sizeof(float));
     const void *mis_f = (const char *)b->lut.p + 256 * (2 * sizeof(double) + sizeof(float));
     const bool f32_family = b->precision == AGX_PHMM_F32 || b->precision == AGX_PHMM_F32_FMA;
-    if (f32_family) AGX_HIP(hipMemsetAsync(b->counter.p, 0, 2 * sizeof(unsigned long long), s));
+    // The two counters are zero at creation and are reset by whoever reads them (the log10 kernel of agx_phmm_batch_results; a
+    // bound batch whose flag stayed clear has counted nothing): only a launch whose predecessor's counts nobody took resets
+    // them itself.
+    if (f32_family && b->counters_dirty) AGX_HIP(hipMemsetAsync(b->counter.p, 0, 2 * sizeof(unsigned long long), s));
+    b->counters_dirty = f32_family;
     b->rescue_pending = b->separate_rescue;
     if (b->bound) *(volatile unsigned *)b->bound_flag.p = 0; // set by the fill when a pair goes to the rescue plan
     const void *mis_for_d = b->gatk_prior ? mis_d : nullptr, *mis_for_f = b->gatk_prior ? mis_f : nullptr;
@@ -1502,6 +1507,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
         if (*(volatile unsigned *)b->bound_flag.p == 0) {
             b->rescue_pending = false;
             b->info.n_rescued = 0;
+            b->counters_dirty = false; // no pair was counted: the counters are still zero
             return AGX_OK;
         }
     }
@@ -1524,7 +1530,7 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
             // page-locked (agx_host_alloc), else the staging block: consecutive 8-byte stores, no D2H copy behind it
             dev_logs = agx_is_pinned_host(log10_lik, sum_bytes) ? log10_lik : (double *)at;
             if (agx_phmm_finish_launch((const double *)b->sums.p, dev_logs, (uint32_t)b->n_pairs, c64, c32,
-                                       (const unsigned long long *)b->counter.p, (unsigned long long *)stage, st)) {
+                                       (unsigned long long *)b->counter.p, (unsigned long long *)stage, st)) {
                 agx_set_error("phmm_finish launch failed: %s", hipGetErrorString(hipGetLastError()));
                 return AGX_E_HIP;
             }
@@ -1547,7 +1553,11 @@ int agx_phmm_batch_results(agx_phmm_batch *b, double *log10_lik, double *raw_sum
         if (rc) return rc;
     }
     b->rescue_pending = false;
-    b->info.n_rescued = (int64_t)host_counter[0];
+    if (f32 && b->n_pairs) {
+        if (b->counters_dirty) b->info.n_rescued = (int64_t)host_counter[0]; // (a second fetch without a launch in between finds them reset: the figure stays)
+        b->counters_dirty = false;
+    } else
+        b->info.n_rescued = (int64_t)host_counter[0];
     if (f32) {
         if (b->n_pairs && dev_logs != log10_lik) memcpy(log10_lik, dev_logs, sum_bytes);
     } else

@@ -159,8 +159,9 @@ void agx_phmm_lut_preload();
 void agx_phmm_pk_preload();
 void agx_phmm_scalar_preload();
 void agx_phmm_finish_preload();
+// (copies the two counters to the host and RESETS them)
 int agx_phmm_finish_launch(const double *sums, double *logs, uint32_t n, double log_c64, double log_c32,
-                           const unsigned long long *n_rescued, unsigned long long *n_rescued_host, hipStream_t s);
+                           unsigned long long *n_rescued, unsigned long long *n_rescued_host, hipStream_t s);
 int agx_phmm_launch_class(int mode, int cols_per_lane, bool all_groups_16, const uint32_t *img, const PhGroup *groups, const PhTab *tabs,
                           const PhWave *waves, uint32_t n_waves, const void *lut, const void *lut_mis, double *sums,
                           double rescue_below,
