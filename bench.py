@@ -620,7 +620,7 @@ def main():
                          scores_identical_to_packed=i32_same, useful_cell_fraction=i32_info.cells / max(1, i32_info.padded_cells),
                          roofline=roof(sw.algorithmic_bytes(), i32_t["launch_ms"], "sw_fill_int32", i32_t["back_to_back_launch_ms"])),
         "pairhmm": dict(ph_leg, metric="PairHMM forward pairs/s (config 3: 65536 pairs R=100 H=300 fp32 per GPU)", unit="pairs/s",
-                        dtype="f32 (two haplotypes per lane group, packed FMA; double rescue)",
+                        dtype="f32 (two haplotypes per lane group, packed FMA, two reads per group behind one another (read trains); double rescue)",
                         gcups=n_gpus * ph.cells() * ph_t["steps"] / ph_t["dt"] / 1e9, rescued_in_f64=int(ph_rescued),
                         waves=ph_info.n_waves, launches_per_step=ph_info.n_launches,
                         useful_cell_fraction=ph_info.cells / max(1, ph_info.padded_cells),
