@@ -396,7 +396,7 @@ def main():
                                                      "mean": float(per.mean()) * 1e3, "max": float(per.max()) * 1e3},
                 "launch_ms": float(kern.mean()), "launch_ms_min": float(kern.min()), "back_to_back_launch_ms": b2b}
 
-    few = lambda: (max(10, args.steps // 10), max(2, args.warmup // 10))
+    few = lambda: (max(20, args.steps // 5), max(3, args.warmup // 5))  # (the other legs: 20 steps -- one slow step among ten moved a leg by 5-8 % from run to run)
     traffic = {}
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
