@@ -400,11 +400,24 @@ def test_read_trains_change_nothing(ctx, oracle):
         assert np.array_equal(out[:p.n_pairs], plain) and np.all(out[p.n_pairs:] == 7.0)
     finally:
         ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_AUTO)
-    # the default: config 3's shape and size forms trains by itself, small batches do not
+    # the default: config 3's shape and size forms trains by itself, small batches do not; at that size too the sums are
+    # the plain schedule's bit for bit (all 65 536 pairs)
     big = synth.phmm_regions(64, 64, 16, 100, 300, seed=3)
     dev = ctx.phmm_batch(big, agx.PHMM_F32_FMA)
     assert dev.info().n_waves == 4096
+    dev.launch()
+    l_auto, s_auto = dev.results()
     dev.close()
+    try:
+        ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_OFF)
+        dev = ctx.phmm_batch(big, agx.PHMM_F32_FMA)
+        assert dev.info().n_waves == 8192
+        dev.launch()
+        l_off, s_off = dev.results()
+        dev.close()
+    finally:
+        ctx.set_option(agx.OPT_PHMM_TRAINS, agx.PHMM_TRAINS_AUTO)
+    assert np.array_equal(s_auto, s_off) and np.array_equal(l_auto, l_off)
     small = ctx.phmm_batch(cases[0][1], agx.PHMM_F32_FMA)
     assert small.info().n_waves == waves_off["uniform"]
     small.close()
