@@ -145,7 +145,10 @@ int max_classes()
 
 // Uniform batches (most pairs share one (R, H) shape): the launch lasts ceil(waves / SIMDs)
 // wave-times, so the tiling of that shape is chosen with that quantisation.
-void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count, int n_simd, uint8_t *cls, uint8_t *G_out)
+// pair_reads: the plan will pair reads into trains (packed float fill): a wave then lasts 2 (R + 1) + G - 2 steps and there are
+// half as many -- the quantisation is that of the paired waves (H = 270: 9 lanes x 30 columns are 2341 paired waves, three
+// rounds of which the last is a seventh full, 0.363 ms; 16 x 17 are 4096, four full rounds, 0.286 ms)
+void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count, int n_simd, bool pair_reads, uint8_t *cls, uint8_t *G_out)
 {
     const ClassTable ct = class_table(precision);
     int best = -1, bestG = 0;
@@ -159,9 +162,14 @@ void choose_tiling_uniform(int precision, uint32_t R, uint32_t H, int64_t count,
         const double wgt = ct.cost[ci];
         if (wgt == 0) continue;
         const int64_t per_wave = 64 / G;
-        const int64_t waves = (count + per_wave - 1) / per_wave;
+        int64_t waves = (count + per_wave - 1) / per_wave;
+        uint32_t steps = R + (uint32_t)G - 1u;
+        if (pair_reads && C <= 30) { // (widths 31 and 32 do not pair: see partner_of)
+            waves = (waves + 1) / 2;
+            steps = 2u * (R + 1u) + (uint32_t)G - 2u;
+        }
         const int64_t rounds = (waves + n_simd - 1) / n_simd;
-        const double cost = (double)rounds * (R + G - 1) * C * wgt;
+        const double cost = (double)rounds * steps * C * wgt;
         if (best < 0 || cost < best_cost) {
             best = ci;
             bestG = G;
@@ -457,7 +465,8 @@ int make_plan(const PlanSeed &seed, std::vector<Plan> gen, int kind, int slots, 
             });
         if (votes > 0 && count.load() * 2 >= n) {
             uint8_t c = 255, G = 0;
-            choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count.load() + slots - 1) / slots, 4 * n_cu, &c, &G);
+            const bool pair_reads = slots == 2 && trains != 1 && (trains == 2 || waves_est >= 16.0 * n_cu);
+            choose_tiling_uniform(kind, cand >> 16, cand & 0xffffu, (count.load() + slots - 1) / slots, 4 * n_cu, pair_reads, &c, &G);
             if (c < ct.n)
                 agx_parallel_for(n, 16384, [&](int64_t lo, int64_t hi, int) {
                     for (int64_t k = lo; k < hi; ++k)
